@@ -1,0 +1,218 @@
+"""ctypes wrapper around the CPU oracle (oracle/_build/libnsof_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.  See the headers of
+oracle/farneback_ref.c and oracle/accum_ref.c for what each function restates.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libnsof_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.nsof_ref_farneback_u8.restype = C.c_int
+        _lib.nsof_ref_farneback_u8.argtypes = [
+            C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t,
+            C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        _lib.nsof_ref_pyr_level.restype = C.c_int
+        _lib.nsof_ref_pyr_level.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        _lib.nsof_ref_level_geometry.restype = None
+        _lib.nsof_ref_level_geometry.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 4
+        _lib.nsof_ref_effective_levels.restype = C.c_int
+        _lib.nsof_ref_effective_levels.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int]
+        _lib.nsof_ref_polyexp.restype = C.c_int
+        _lib.nsof_ref_polyexp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        _lib.nsof_ref_update_matrices.restype = C.c_int
+        _lib.nsof_ref_update_matrices.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
+        _lib.nsof_ref_update_flow_blur.restype = C.c_int
+        _lib.nsof_ref_update_flow_blur.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4
+        _lib.nsof_ref_resize_linear.restype = C.c_int
+        _lib.nsof_ref_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        _lib.nsof_ref_gaussian_kernel.restype = C.c_int
+        _lib.nsof_ref_gaussian_kernel.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        _lib.nsof_ref_poly_prepare.restype = C.c_int
+        _lib.nsof_ref_poly_prepare.argtypes = [C.c_int, C.c_double] + [C.c_void_p] * 4
+        if hasattr(_lib, "nsof_ref_accum_update_state"):
+            _bind_accum(_lib)
+    return _lib
+
+
+def _bind_accum(l):
+    l.nsof_ref_accum_update_state.restype = None
+    l.nsof_ref_accum_update_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    l.nsof_ref_accum_resistance.restype = None
+    l.nsof_ref_accum_resistance.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    l.nsof_ref_accum_slice_bounds.restype = C.c_int64
+    l.nsof_ref_accum_slice_bounds.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
+    l.nsof_ref_accum_simulate.restype = C.c_int
+    l.nsof_ref_accum_simulate.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+        C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed: rc={rc}")
+
+
+def _u8(a):
+    a = np.asarray(a)
+    assert a.dtype == np.uint8 and a.ndim == 2 and a.strides[1] == 1
+    return a
+
+
+# ---------------------------------------------------------------- Farneback
+def farneback(prev, nxt, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags=0):
+    prev, nxt = _u8(prev), _u8(nxt)
+    h, w = prev.shape
+    flow = np.empty((h, w, 2), np.float32)
+    rc = lib().nsof_ref_farneback_u8(prev.ctypes.data, prev.strides[0], nxt.ctypes.data, nxt.strides[0], w, h,
+                                     flow.ctypes.data, flow.strides[0], pyr_scale, levels, winsize, iterations,
+                                     poly_n, poly_sigma, flags)
+    _chk(rc, "farneback")
+    return flow
+
+
+def effective_levels(w, h, pyr_scale, levels):
+    return lib().nsof_ref_effective_levels(w, h, pyr_scale, levels)
+
+
+def level_geometry(w, h, pyr_scale, k):
+    wk, hk, ks = C.c_int(), C.c_int(), C.c_int()
+    sg = C.c_double()
+    lib().nsof_ref_level_geometry(w, h, pyr_scale, k, C.byref(wk), C.byref(hk), C.byref(ks), C.byref(sg))
+    return wk.value, hk.value, ks.value, sg.value
+
+
+def pyr_level(img, pyr_scale, k):
+    img = _u8(img)
+    h, w = img.shape
+    wk, hk, _, _ = level_geometry(w, h, pyr_scale, k)
+    out = np.empty((hk, wk), np.float32)
+    _chk(lib().nsof_ref_pyr_level(img.ctypes.data, img.strides[0], w, h, pyr_scale, k, out.ctypes.data), "pyr_level")
+    return out
+
+
+def polyexp(img_f32, n, sigma):
+    a = np.ascontiguousarray(img_f32, np.float32)
+    h, w = a.shape
+    out = np.empty((h, w, 5), np.float32)
+    _chk(lib().nsof_ref_polyexp(a.ctypes.data, w, h, n, sigma, out.ctypes.data), "polyexp")
+    return out
+
+
+def update_matrices(R0, R1, flow, M=None, y0=0, y1=None):
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w = flow.shape[:2]
+    if M is None:
+        M = np.zeros((h, w, 5), np.float32)
+    _chk(lib().nsof_ref_update_matrices(R0.ctypes.data, R1.ctypes.data, flow.ctypes.data, M.ctypes.data, w, h, y0,
+                                        h if y1 is None else y1), "update_matrices")
+    return M
+
+
+def update_flow_blur(R0, R1, flow, M, winsize, update):
+    """Returns (new_flow, new_M); inputs are not modified."""
+    R0 = np.ascontiguousarray(R0, np.float32)
+    R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.array(flow, np.float32, order="C")
+    M = np.array(M, np.float32, order="C")
+    h, w = flow.shape[:2]
+    _chk(lib().nsof_ref_update_flow_blur(R0.ctypes.data, R1.ctypes.data, flow.ctypes.data, M.ctypes.data, w, h,
+                                         winsize, int(bool(update))), "update_flow_blur")
+    return flow, M
+
+
+def resize_linear(src, dw, dh):
+    a = np.ascontiguousarray(src, np.float32)
+    sh, sw = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    out = np.empty((dh, dw) if a.ndim == 2 else (dh, dw, cn), np.float32)
+    _chk(lib().nsof_ref_resize_linear(a.ctypes.data, sw, sh, cn, out.ctypes.data, dw, dh), "resize")
+    return out
+
+
+def gaussian_kernel(n, sigma):
+    out = np.empty(n, np.float32)
+    _chk(lib().nsof_ref_gaussian_kernel(n, sigma, out.ctypes.data), "gaussian_kernel")
+    return out
+
+
+def poly_prepare(n, sigma):
+    g = np.empty(2 * n + 1, np.float32)
+    xg = np.empty_like(g)
+    xxg = np.empty_like(g)
+    ig = np.empty(4, np.float64)
+    _chk(lib().nsof_ref_poly_prepare(n, sigma, g.ctypes.data, xg.ctypes.data, xxg.ctypes.data, ig.ctypes.data),
+         "poly_prepare")
+    return g, xg, xxg, ig
+
+
+# ---------------------------------------------------------------- accumulator
+def accum_update_state(w, V):
+    w = np.ascontiguousarray(w, np.float32)
+    V = np.ascontiguousarray(V, np.float32)
+    out = np.empty_like(w)
+    lib().nsof_ref_accum_update_state(w.ctypes.data, V.ctypes.data, out.ctypes.data, w.size)
+    return out
+
+
+def accum_resistance(w):
+    w = np.ascontiguousarray(w, np.float32)
+    out = np.empty_like(w)
+    lib().nsof_ref_accum_resistance(w.ctypes.data, out.ctypes.data, w.size)
+    return out
+
+
+def accum_slice_bounds(t, slice_us):
+    t = np.ascontiguousarray(t, np.int64)
+    n = lib().nsof_ref_accum_slice_bounds(t.ctypes.data, t.size, slice_us, None, 0)
+    idx = np.empty(n, np.int64)
+    lib().nsof_ref_accum_slice_bounds(t.ctypes.data, t.size, slice_us, idx.ctypes.data, n)
+    return idx
+
+
+def accum_simulate(x, y, p, t, H, W, version, polarity, slice_us, active_v, silent_v):
+    """polarity: 'split' | 'magnitude'.  Returns dict(w_final, resistances[, w_final_b, resistances_b])."""
+    x = np.ascontiguousarray(x, np.int16)
+    y = np.ascontiguousarray(y, np.int16)
+    p = np.ascontiguousarray(p, np.int8)
+    t = np.ascontiguousarray(t, np.int64)
+    idx = accum_slice_bounds(t, slice_us)
+    nslices = max(len(idx) - 1, 0)
+    every = max(1, nslices // 100)
+    nsnap = (nslices + every - 1) // every
+    split = 1 if (version == 2 and polarity == "split") else 0
+    wa = np.empty((H, W), np.float32)
+    ra = np.empty((nsnap, H, W), np.float32)
+    wb = np.empty((H, W), np.float32) if split else None
+    rb = np.empty((nsnap, H, W), np.float32) if split else None
+    rc = lib().nsof_ref_accum_simulate(
+        x.ctypes.data, y.ctypes.data, p.ctypes.data, t.ctypes.data, t.size, H, W, version, split, slice_us,
+        active_v, silent_v, wa.ctypes.data, ra.ctypes.data, wb.ctypes.data if split else None,
+        rb.ctypes.data if split else None, nsnap)
+    _chk(rc, "accum_simulate")
+    out = dict(w_final=wa, resistances=ra)
+    if split:
+        out.update(w_final_b=wb, resistances_b=rb)
+    return out
