@@ -1,0 +1,156 @@
+/*
+ * nsof.h -- C ABI of libnsof.so, the MI355X (gfx950) neuromorphic optical-flow core.
+ *
+ * This is the drop-in boundary for the two data-parallel stages of
+ * RTCartist/Neuromorphic-Spatiotemporal-Optical-Flow (paths below are relative to the
+ * reference checkout):
+ *
+ *   stage 2  dense Farneback flow -- replaces `cv2.calcOpticalFlowFarneback(prev, next,
+ *            None, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)`
+ *            called at optical_flow_seg.py:158,203,494, optical_flow_ob.py:225,270,616,
+ *            optical_flow_prediction.py:161,206,570, optical_flow_yolo.py:199,244,898
+ *            (parameter dict: optical_flow_seg.py:73-81).
+ *   stage 1  synaptic accumulator -- replaces update_state / resistance_exp / simulate of
+ *            eventsim/event_mem_sim.py:40-57, :60-63, :164-286.
+ *
+ * Plain C types only; no torch / numpy types cross this boundary.  All entry points
+ * return NSOF_OK (0) or a negative nsof_status; nsof_last_error() gives the text.
+ * A context owns one device, one HIP stream and a reusable workspace; it is not
+ * thread-safe, several contexts may coexist.  There is no CPU fallback: without a
+ * usable gfx950 device nsof_create() fails with NSOF_EDEVICE.
+ */
+#ifndef NSOF_H
+#define NSOF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSOF_ABI_VERSION 1
+
+typedef enum nsof_status {
+    NSOF_OK = 0,
+    NSOF_EINVAL = -1,       /* bad argument (cv2 would raise cv2.error on its CV_Assert) */
+    NSOF_ESHAPE = -2,       /* prev/next shapes differ or are empty */
+    NSOF_EDEVICE = -3,      /* HIP runtime / device failure, or no gfx950 device */
+    NSOF_ENOMEM = -4,       /* host or device allocation failed */
+    NSOF_EUNSUPPORTED = -5  /* flags the reference never uses (USE_INITIAL_FLOW=4, FARNEBACK_GAUSSIAN=256) */
+} nsof_status;
+
+typedef struct nsof_ctx nsof_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* device: HIP device ordinal.  *out receives the context. */
+int nsof_create(int device, nsof_ctx** out);
+void nsof_destroy(nsof_ctx* ctx);
+/* Text of the last error on this context (or of the last failed nsof_create if ctx==NULL). */
+const char* nsof_last_error(const nsof_ctx* ctx);
+int nsof_abi_version(void);
+/* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> own stream. */
+int nsof_set_stream(nsof_ctx* ctx, void* hip_stream);
+int nsof_synchronize(nsof_ctx* ctx);
+
+/* ---- stage 2: Farneback --------------------------------------------------------------- */
+/* Same argument meaning and order as cv2.calcOpticalFlowFarneback (see call sites above).
+ * prev/next: HOST uint8 single-channel images, row strides in bytes (strided ROI views are
+ * fine, optical_flow_seg.py:186-187); flow: HOST float32, interleaved (u,v), row stride in
+ * bytes.  Pointers are not retained.  Blocks until the flow is in host memory. */
+int nsof_farneback_u8(nsof_ctx* ctx,
+                      const uint8_t* prev, ptrdiff_t prev_stride,
+                      const uint8_t* next, ptrdiff_t next_stride,
+                      int width, int height,
+                      float* flow, ptrdiff_t flow_stride,
+                      double pyr_scale, int levels, int winsize, int iterations,
+                      int poly_n, double poly_sigma, int flags);
+
+/* Batched, device-resident twin: n_pairs frame pairs of one shape already in HBM.
+ * d_prev/d_next: DEVICE uint8 [n_pairs][height][row_stride]; pair_stride in bytes.
+ * d_flow: DEVICE float32 [n_pairs][height][width][2] (dense).  Asynchronous on the
+ * context's stream. */
+int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs,
+                                const uint8_t* d_prev, const uint8_t* d_next,
+                                ptrdiff_t row_stride, ptrdiff_t pair_stride,
+                                int width, int height, float* d_flow,
+                                double pyr_scale, int levels, int winsize, int iterations,
+                                int poly_n, double poly_sigma, int flags);
+
+/* Geometry helpers (pure host arithmetic, usable without a device: ctx may be NULL). */
+int nsof_farneback_effective_levels(int width, int height, double pyr_scale, int levels);
+int nsof_farneback_level_size(int width, int height, double pyr_scale, int level,
+                              int* level_width, int* level_height, int* blur_ksize, double* blur_sigma);
+
+/* Individual pipeline stages on DEVICE buffers, exposed for stage-level parity tests and
+ * for the roofline benchmark.  Planar layouts: R and M are [n_img][5][h][w] float32,
+ * images [n_img][h][w] float32, flow [n_img][h][w][2] float32. */
+int nsof_stage_pyr_level(nsof_ctx* ctx, int n_img, const uint8_t* d_src, ptrdiff_t row_stride,
+                         ptrdiff_t img_stride, int width, int height, double pyr_scale, int level, float* d_out);
+int nsof_stage_polyexp(nsof_ctx* ctx, int n_img, const float* d_img, int width, int height,
+                       int poly_n, double poly_sigma, float* d_R);
+/* n_pairs pairs: R holds [n_pairs][2][5][h][w] (image 0 = prev, 1 = next). */
+int nsof_stage_update_matrices(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_flow,
+                               int width, int height, float* d_M);
+int nsof_stage_blur_solve(nsof_ctx* ctx, int n_pairs, const float* d_M, int width, int height,
+                          int winsize, float* d_flow);
+int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* d_src, int src_w, int src_h,
+                             float* d_dst, int dst_w, int dst_h, double pyr_scale);
+
+/* ---- profiling (HIP events on the context's stream, around every launch of one kernel) -- */
+typedef enum nsof_kernel_id {
+    NSOF_K_PREP = 0,        /* u8 -> f32, Gaussian blur, bilinear resample (per level) */
+    NSOF_K_POLYEXP = 1,     /* polynomial expansion */
+    NSOF_K_UPSAMPLE = 2,    /* coarse-to-fine flow resample */
+    NSOF_K_UPDMAT = 3,      /* matrix update with warped R1 */
+    NSOF_K_BLUR = 4,        /* box blur + 2x2 solve */
+    NSOF_K_ACCUM = 5,       /* accumulator state update */
+    NSOF_K_COUNT = 6
+} nsof_kernel_id;
+/* mask: bit (1<<id) enables event bracketing for that kernel; 0 disables. */
+int nsof_prof_enable(nsof_ctx* ctx, unsigned mask);
+/* Synchronises, then returns summed device time (ms) and launch count since the last call. */
+int nsof_prof_collect(nsof_ctx* ctx, int kernel_id, double* total_ms, long long* launches);
+const char* nsof_kernel_name(int kernel_id);
+
+/* ---- stage 1: synaptic accumulator ---------------------------------------------------- */
+typedef struct nsof_accum nsof_accum;
+
+/* Device constants follow event_mem_sim.py:20-34 (PARAMS, DT=5e-4, THETA_EVENTS=1,
+ * REFRACTORY_US=800).  scheme: 1 = boxcar window, 2 = DC bias + event overlay (:208-286).
+ * polarity_split: scheme 2 only -- 1 = 'split' (ON p==1 -> array A, OFF p==0 -> array B),
+ * 0 = 'magnitude' (one array). */
+int nsof_accum_create(nsof_ctx* ctx, int height, int width, int scheme, int polarity_split,
+                      float active_v, float silent_v, nsof_accum** out);
+void nsof_accum_destroy(nsof_accum* acc);
+/* force_dense != 0: always run the dense fused update (every pixel visited) even when silent_v
+ * lies in the dead zone and the sparse event-pixel path would be exact -- the roofline run. */
+int nsof_accum_set_dense(nsof_accum* acc, int force_dense);
+/* Reset w to wini (0.5) and the refractory maps to 0. */
+int nsof_accum_reset(nsof_accum* acc);
+/* Advance by n_slices time slices.  Events are HOST arrays (x,y int16; p int8; t int64 us,
+ * sorted) as in the /CD/events group (event_mem_sim.py:69-75); slice_bounds has
+ * n_slices+1 entries: slice i covers events [slice_bounds[i], slice_bounds[i+1]).  If
+ * snap_every > 0, after every slice whose global index (counted since reset) is a multiple
+ * of snap_every a resistance snapshot is appended to the snapshot ring. */
+int nsof_accum_step_events(nsof_accum* acc, const int16_t* x, const int16_t* y, const int8_t* p,
+                           const int64_t* t, const int64_t* slice_bounds, int64_t n_slices,
+                           int64_t snap_every);
+/* Dense element-wise update_state on DEVICE arrays (event_mem_sim.py:40-57). */
+int nsof_accum_update_state_dev(nsof_ctx* ctx, const float* d_w, const float* d_V, float* d_out, size_t n);
+/* Dense resistance_exp on DEVICE arrays (event_mem_sim.py:60-63). */
+int nsof_accum_resistance_dev(nsof_ctx* ctx, const float* d_w, float* d_out, size_t n);
+/* Copy state to HOST: which = 0 (array A) or 1 (array B, split mode). */
+int nsof_accum_read_w(nsof_accum* acc, int which, float* w_out);
+int nsof_accum_read_resistance(nsof_accum* acc, int which, float* r_out);
+/* Snapshots taken so far; copy them ([count][H][W] float32) to HOST and clear the ring. */
+int64_t nsof_accum_snapshot_count(const nsof_accum* acc);
+int nsof_accum_read_snapshots(nsof_accum* acc, int which, float* out, int64_t max_count);
+/* slice_indices() of event_mem_sim.py:78-83 on a HOST timestamp array: returns the number
+ * of bounds and fills idx (if not NULL) with up to cap entries. */
+int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t slice_us, int64_t* idx, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSOF_H */

@@ -1,0 +1,504 @@
+// Synaptic accumulator ("memristor array"): HIP kernels + host driver for gfx950.
+//
+// Replaces /root/reference/eventsim/event_mem_sim.py: update_state (:40-57),
+// resistance_exp (:60-63) and the slice loop of simulate (:164-286).
+//
+// Design (MI355X-first, not a translation of the per-slice NumPy passes):
+//  * Pixels are independent and time is serial per pixel, so up to 32 consecutive slices are
+//    fused into ONE pass over the state: a scatter kernel ORs "pixel active in slice s" bits
+//    into a u32 mask per pixel; the update kernel reads w once, replays the 32 slices in
+//    registers and writes w once.  HBM traffic drops from 8 B/px/slice to <= 16/S B/px/slice.
+//  * When silent_v lies in the device's dead zone [voff, von] (the default, 0 V) an inactive
+//    pixel is a bit-exact no-op (dw/dt = 0, clip is the identity on [0,1]); then only the
+//    pixels touched by events are visited (compacted list built by the scatter kernel).
+//  * Scheme 2's refractory rule couples consecutive slices through next_ok, so its scatter
+//    runs one (tiny) launch per slice in stream order; the state update is still fused.
+//  * pow/exp go through double precision so that the float32 result is the correctly
+//    rounded one in all but ~1e-9 of cases (the reference's NumPy uses SIMD pow/exp that are
+//    themselves 1-4 ulp off libm; tolerances are stated in tests/test_accum_*.py).
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "nsof_internal.h"
+
+namespace {
+
+// event_mem_sim.py:20-34
+constexpr float VOFF = (float)-0.2, VON = (float)0.1;
+constexpr float KOFF = (float)51.03, KON = (float)-2.91;
+constexpr float SON = (float)0.2, SOFF = (float)0.8;
+constexpr float BON = (float)-5.12, BOFF = (float)3.10;
+constexpr float DT = (float)5e-4;
+constexpr double RON = 163305.0, ROFF = 2104377.0;
+constexpr long long REFRACTORY_US = 800;
+constexpr float WINI = 0.5f;
+constexpr int MAX_GROUP = 32;
+
+__device__ __forceinline__ float pow_f32(float x, float b)
+{
+    // x > 0 on every path that reaches here (1 - w*s with w in [0,1], s < 1)
+    return (float)exp((double)b * log((double)x));
+}
+
+__device__ __forceinline__ float update_one(float w, float V)
+{
+    float dwdt = 0.f;
+    if (V < VOFF) {
+        const float a = V / VOFF - 1.f;
+        const float b = pow_f32(1.f - w * SOFF, BOFF);
+        dwdt = KOFF * a * b;
+    } else if (V > VON) {
+        const float a = V / VON - 1.f;
+        const float b = pow_f32(1.f - w * SON, BON);
+        dwdt = KON * a * b;
+    }
+    const float wn = w + dwdt * DT;
+    return wn < 0.f ? 0.f : (wn > 1.f ? 1.f : wn);
+}
+
+__device__ __forceinline__ float resistance_one(float w, float neg_lam)
+{
+    const float e = (float)exp((double)(neg_lam * (1.0f - w)));
+    return (float)(RON / (double)e);
+}
+
+__global__ __launch_bounds__(256) void k_update_state(const float* __restrict__ w, const float* __restrict__ V,
+                                                       float* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = update_one(w[i], V[i]);
+}
+
+__global__ __launch_bounds__(256) void k_resistance(const float* __restrict__ w, float* __restrict__ out, size_t n,
+                                                     float neg_lam)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = resistance_one(w[i], neg_lam);
+}
+
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+
+__device__ __forceinline__ void mark(unsigned* mask, unsigned* list, unsigned* count, unsigned pix, unsigned bit)
+{
+    const unsigned old = atomicOr(&mask[pix], bit);
+    if (old == 0) list[atomicAdd(count, 1u)] = pix;  // first touch in this group: enters the compact list once
+}
+
+// Scheme 1 (:208-217): every event of the group marks (pixel, its slice).  bounds = event
+// indices of the group's slice boundaries (n_sl+1 entries), relative to ev0.
+__global__ __launch_bounds__(256) void k_scatter_v1(const short* __restrict__ x, const short* __restrict__ y,
+                                                     long long ev0, long long n_ev, const long long* __restrict__ bounds,
+                                                     int n_sl, int W, unsigned* mask, unsigned* list, unsigned* count)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ev) return;
+    const long long e = ev0 + i;
+    int lo = 0, hi = n_sl;  // largest s with bounds[s] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bounds[mid] <= e) lo = mid; else hi = mid;
+    }
+    mark(mask, list, count, (unsigned)y[e] * (unsigned)W + (unsigned)x[e], 1u << lo);
+}
+
+// Scheme 2 (:237-269), one slice: eligible <=> next_ok[pix] <= t_first; eligible pixels are
+// marked once and get next_ok = t_last + REFRACTORY.  A racing thread of the same slice may
+// already see the new next_ok (> t_first) and skip -- the pixel is marked either way.
+// pol_sel: -1 = any polarity (magnitude mode), else only events with p == pol_sel.
+__global__ __launch_bounds__(256) void k_scatter_v2(const short* __restrict__ x, const short* __restrict__ y,
+                                                     const signed char* __restrict__ p, long long ev0, long long n_ev,
+                                                     int pol_sel, long long t_first, long long t_next, int W,
+                                                     unsigned bit, long long* next_ok, unsigned* mask, unsigned* list,
+                                                     unsigned* count)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ev) return;
+    const long long e = ev0 + i;
+    if (pol_sel >= 0 && (int)p[e] != pol_sel) return;
+    const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
+    const long long ok = __hip_atomic_load(&next_ok[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ok <= t_first) {
+        __hip_atomic_store(&next_ok[pix], t_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mark(mask, list, count, pix, bit);
+    }
+}
+
+// Fused state update over the touched pixels only (silent_v inside the dead zone).
+__global__ __launch_bounds__(256) void k_update_sparse(float* __restrict__ w, unsigned* __restrict__ mask,
+                                                        const unsigned* __restrict__ list,
+                                                        const unsigned* __restrict__ count, int n_sl, float v_act)
+{
+    const unsigned n = *count;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned pix = list[i];
+        unsigned m = mask[pix];
+        mask[pix] = 0;
+        float ww = w[pix];
+        for (int s = 0; s < n_sl; s++, m >>= 1)
+            if (m & 1u) ww = update_one(ww, v_act);
+        w[pix] = ww;
+    }
+}
+
+// Fused state update over every pixel (silent_v outside the dead zone, or forced dense).
+// 4 pixels per thread: one 16-B load/store of w and of the mask per lane.
+__global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, unsigned* __restrict__ mask, size_t n4,
+                                                       size_t n, int n_sl, float v_act, float v_sil)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        if (4 * i + 3 < n) {
+            float4 ww = reinterpret_cast<float4*>(w)[i];
+            uint4 mm = reinterpret_cast<uint4*>(mask)[i];
+            if (mm.x | mm.y | mm.z | mm.w) reinterpret_cast<uint4*>(mask)[i] = make_uint4(0, 0, 0, 0);
+            for (int s = 0; s < n_sl; s++) {
+                ww.x = update_one(ww.x, (mm.x >> s) & 1u ? v_act : v_sil);
+                ww.y = update_one(ww.y, (mm.y >> s) & 1u ? v_act : v_sil);
+                ww.z = update_one(ww.z, (mm.z >> s) & 1u ? v_act : v_sil);
+                ww.w = update_one(ww.w, (mm.w >> s) & 1u ? v_act : v_sil);
+            }
+            reinterpret_cast<float4*>(w)[i] = ww;
+        } else {
+            for (size_t j = 4 * i; j < n; j++) {
+                unsigned m = mask[j];
+                mask[j] = 0;
+                float ww = w[j];
+                for (int s = 0; s < n_sl; s++) ww = update_one(ww, (m >> s) & 1u ? v_act : v_sil);
+                w[j] = ww;
+            }
+        }
+    }
+}
+
+inline int grid_for(size_t n, int cap = 4096)
+{
+    size_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
+}  // namespace
+
+struct nsof_accum {
+    nsof_ctx* ctx = nullptr;
+    int H = 0, W = 0, scheme = 1, split = 0;
+    float active_v = 0, silent_v = 0;
+    bool force_dense = false;
+    size_t npx = 0;
+    float* w[2] = {nullptr, nullptr};
+    long long* next_ok[2] = {nullptr, nullptr};
+    unsigned* mask[2] = {nullptr, nullptr};
+    unsigned* list[2] = {nullptr, nullptr};
+    size_t list_cap = 0;
+    unsigned* count = nullptr;  // [2]
+    // event staging
+    short *dx = nullptr, *dy = nullptr;
+    signed char* dp = nullptr;
+    long long* dbounds = nullptr;
+    size_t ev_cap = 0, bounds_cap = 0;
+    // snapshots
+    float* snap[2] = {nullptr, nullptr};
+    int64_t snap_cap = 0, snap_count = 0;
+    int64_t slice_counter = 0;
+};
+
+static int accum_alloc(nsof_ctx* ctx, void** p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return nsof_set_error(ctx, NSOF_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return NSOF_OK;
+}
+
+extern "C" void nsof_accum_destroy(nsof_accum* a)
+{
+    if (!a) return;
+    hipSetDevice(a->ctx->device);
+    hipStreamSynchronize(a->ctx->stream);
+    for (int i = 0; i < 2; i++) {
+        hipFree(a->w[i]); hipFree(a->next_ok[i]); hipFree(a->mask[i]); hipFree(a->list[i]); hipFree(a->snap[i]);
+    }
+    hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
+    delete a;
+}
+
+extern "C" int nsof_accum_reset(nsof_accum* a)
+{
+    if (!a) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const int narr = a->split ? 2 : 1;
+    for (int i = 0; i < narr; i++) {
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(a->npx)), dim3(256), 0, ctx->stream, a->w[i], a->npx, WINI);
+        NSOF_HIP(ctx, hipMemsetAsync(a->mask[i], 0, a->npx * sizeof(unsigned), ctx->stream));
+        if (a->scheme == 2) NSOF_HIP(ctx, hipMemsetAsync(a->next_ok[i], 0, a->npx * sizeof(long long), ctx->stream));
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    a->slice_counter = 0;
+    a->snap_count = 0;
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_create(nsof_ctx* ctx, int height, int width, int scheme, int polarity_split, float active_v,
+                                 float silent_v, nsof_accum** out)
+{
+    if (!ctx || !out) return NSOF_EINVAL;
+    *out = nullptr;
+    if (height < 1 || width < 1 || (scheme != 1 && scheme != 2))
+        return nsof_set_error(ctx, NSOF_EINVAL, "bad accumulator geometry %dx%d or scheme %d", height, width, scheme);
+    if ((size_t)height * width > 0xFFFFFFFFull) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "sensor too large");
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    nsof_accum* a = new (std::nothrow) nsof_accum();
+    if (!a) return nsof_set_error(ctx, NSOF_ENOMEM, "out of host memory");
+    a->ctx = ctx; a->H = height; a->W = width; a->scheme = scheme;
+    a->split = (scheme == 2 && polarity_split) ? 1 : 0;
+    a->active_v = active_v; a->silent_v = silent_v;
+    a->npx = (size_t)height * width;
+    const int narr = a->split ? 2 : 1;
+    int rc = accum_alloc(ctx, (void**)&a->count, 2 * sizeof(unsigned));
+    for (int i = 0; i < narr && !rc; i++) {
+        rc = accum_alloc(ctx, (void**)&a->w[i], (a->npx + 4) * sizeof(float));
+        if (!rc) rc = accum_alloc(ctx, (void**)&a->mask[i], (a->npx + 4) * sizeof(unsigned));
+        if (!rc && scheme == 2) rc = accum_alloc(ctx, (void**)&a->next_ok[i], a->npx * sizeof(long long));
+    }
+    if (!rc) rc = nsof_accum_reset(a);
+    if (rc) { nsof_accum_destroy(a); return rc; }
+    *out = a;
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_set_dense(nsof_accum* a, int force_dense)
+{
+    if (!a) return NSOF_EINVAL;
+    a->force_dense = force_dense != 0;
+    return NSOF_OK;
+}
+
+static int accum_snapshot(nsof_accum* a)
+{
+    nsof_ctx* ctx = a->ctx;
+    const int narr = a->split ? 2 : 1;
+    if (a->snap_count == a->snap_cap) {
+        const int64_t ncap = a->snap_cap ? a->snap_cap * 2 : 16;
+        for (int i = 0; i < narr; i++) {
+            float* nb = nullptr;
+            int rc = accum_alloc(ctx, (void**)&nb, (size_t)ncap * a->npx * sizeof(float));
+            if (rc) return rc;
+            if (a->snap_count)
+                NSOF_HIP(ctx, hipMemcpyAsync(nb, a->snap[i], (size_t)a->snap_count * a->npx * sizeof(float),
+                                             hipMemcpyDeviceToDevice, ctx->stream));
+            NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(a->snap[i]);
+            a->snap[i] = nb;
+        }
+        a->snap_cap = ncap;
+    }
+    const float neg_lam = (float)(-std::log(ROFF / RON));
+    for (int i = 0; i < narr; i++)
+        hipLaunchKernelGGL(k_resistance, dim3(grid_for(a->npx)), dim3(256), 0, ctx->stream, a->w[i],
+                           a->snap[i] + (size_t)a->snap_count * a->npx, a->npx, neg_lam);
+    NSOF_HIP(ctx, hipGetLastError());
+    a->snap_count++;
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int16_t* y, const int8_t* p,
+                                      const int64_t* t, const int64_t* sb, int64_t n_slices, int64_t snap_every)
+{
+    if (!a) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    if (n_slices < 0 || !sb) return nsof_set_error(ctx, NSOF_EINVAL, "bad slice bounds");
+    if (n_slices == 0) return NSOF_OK;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t e0 = sb[0], e1 = sb[n_slices], n_ev = e1 - e0;
+    if (n_ev < 0) return nsof_set_error(ctx, NSOF_EINVAL, "slice bounds not monotone");
+    if (n_ev > 0 && (!x || !y || !t || (a->scheme == 2 && a->split && !p)))
+        return nsof_set_error(ctx, NSOF_EINVAL, "null event array");
+    for (int64_t s = 0; s < n_slices; s++)
+        if (sb[s + 1] < sb[s]) return nsof_set_error(ctx, NSOF_EINVAL, "slice bounds not monotone");
+    // validate coordinates on the host: an out-of-range event would be an out-of-bounds store on the device
+    for (int64_t e = e0; e < e1; e++)
+        if ((unsigned)x[e] >= (unsigned)a->W || (unsigned)y[e] >= (unsigned)a->H)
+            return nsof_set_error(ctx, NSOF_EINVAL, "event %lld at (%d,%d) outside the %dx%d sensor", (long long)e,
+                                  (int)x[e], (int)y[e], a->W, a->H);
+    const int narr = a->split ? 2 : 1;
+    int rc;
+    // stage events + bounds (relative to e0)
+    if ((size_t)n_ev > a->ev_cap) {
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(a->dx); hipFree(a->dy); hipFree(a->dp);
+        for (int i = 0; i < 2; i++) { hipFree(a->list[i]); a->list[i] = nullptr; }
+        a->dx = a->dy = nullptr; a->dp = nullptr;
+        const size_t cap = (size_t)n_ev + (size_t)n_ev / 4 + 1024;
+        if ((rc = accum_alloc(ctx, (void**)&a->dx, cap * 2)) || (rc = accum_alloc(ctx, (void**)&a->dy, cap * 2)) ||
+            (rc = accum_alloc(ctx, (void**)&a->dp, cap)))
+            return rc;
+        for (int i = 0; i < narr; i++)
+            if ((rc = accum_alloc(ctx, (void**)&a->list[i], cap * sizeof(unsigned)))) return rc;
+        a->ev_cap = cap;
+    }
+    if ((size_t)(n_slices + 1) > a->bounds_cap) {
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(a->dbounds);
+        if ((rc = accum_alloc(ctx, (void**)&a->dbounds, (size_t)(n_slices + 1) * 8))) return rc;
+        a->bounds_cap = (size_t)(n_slices + 1);
+    }
+    if (n_ev > 0) {
+        NSOF_HIP(ctx, hipMemcpyAsync(a->dx, x + e0, (size_t)n_ev * 2, hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipMemcpyAsync(a->dy, y + e0, (size_t)n_ev * 2, hipMemcpyHostToDevice, ctx->stream));
+        if (p) NSOF_HIP(ctx, hipMemcpyAsync(a->dp, p + e0, (size_t)n_ev, hipMemcpyHostToDevice, ctx->stream));
+    }
+    std::vector<long long> rel((size_t)n_slices + 1);
+    for (int64_t s = 0; s <= n_slices; s++) rel[s] = (long long)(sb[s] - e0);
+    NSOF_HIP(ctx, hipMemcpyAsync(a->dbounds, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rel is a stack-lifetime buffer
+
+    const bool dead_zone = !(a->silent_v < VOFF) && !(a->silent_v > VON);
+    const bool sparse = dead_zone && !a->force_dense;
+    const float v_act = a->scheme == 1 ? a->active_v : a->silent_v + a->active_v;
+
+    int64_t s0 = 0;
+    while (s0 < n_slices) {
+        // group = up to 32 slices, ending right after the next snapshot slice
+        int64_t g = n_slices - s0 < MAX_GROUP ? n_slices - s0 : MAX_GROUP;
+        if (snap_every > 0) {
+            const int64_t c = a->slice_counter;
+            const int64_t to_snap = (c % snap_every == 0) ? 1 : (snap_every - c % snap_every) + 1;
+            if (to_snap < g) g = to_snap;
+        }
+        const long long ge0 = rel[s0], ge1 = rel[s0 + g], gn = ge1 - ge0;
+        NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 2 * sizeof(unsigned), ctx->stream));
+        if (gn > 0) {
+            nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+            if (a->scheme == 1) {
+                hipLaunchKernelGGL(k_scatter_v1, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx,
+                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], a->list[0], a->count);
+            } else {
+                for (int64_t s = 0; s < g; s++) {
+                    const long long lo = rel[s0 + s], hi = rel[s0 + s + 1];
+                    if (hi <= lo) continue;
+                    const long long t_first = t[e0 + lo], t_next = t[e0 + hi - 1] + REFRACTORY_US;
+                    const unsigned bit = 1u << s;
+                    const dim3 grid((unsigned)((hi - lo + 255) / 256));
+                    if (a->split) {
+                        hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
+                                           hi - lo, 1, t_first, t_next, a->W, bit, a->next_ok[0], a->mask[0],
+                                           a->list[0], a->count);
+                        hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
+                                           hi - lo, 0, t_first, t_next, a->W, bit, a->next_ok[1], a->mask[1],
+                                           a->list[1], a->count + 1);
+                    } else {
+                        hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
+                                           hi - lo, -1, t_first, t_next, a->W, bit, a->next_ok[0], a->mask[0],
+                                           a->list[0], a->count);
+                    }
+                }
+            }
+            NSOF_HIP(ctx, hipGetLastError());
+        }
+        {
+            nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+            for (int i = 0; i < narr; i++) {
+                if (sparse) {
+                    if (gn > 0)
+                        hipLaunchKernelGGL(k_update_sparse, dim3(grid_for((size_t)gn, 1024)), dim3(256), 0, ctx->stream,
+                                           a->w[i], a->mask[i], a->list[i], a->count + i, (int)g, v_act);
+                } else {
+                    const size_t n4 = (a->npx + 3) / 4;
+                    hipLaunchKernelGGL(k_update_dense, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream, a->w[i],
+                                       a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v);
+                }
+            }
+            NSOF_HIP(ctx, hipGetLastError());
+        }
+        a->slice_counter += g;
+        s0 += g;
+        if (snap_every > 0 && (a->slice_counter - 1) % snap_every == 0)
+            if ((rc = accum_snapshot(a))) return rc;
+    }
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_update_state_dev(nsof_ctx* ctx, const float* d_w, const float* d_V, float* d_out, size_t n)
+{
+    if (!ctx || !d_w || !d_V || !d_out) return NSOF_EINVAL;
+    if (!n) return NSOF_OK;
+    nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+    hipLaunchKernelGGL(k_update_state, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_w, d_V, d_out, n);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_resistance_dev(nsof_ctx* ctx, const float* d_w, float* d_out, size_t n)
+{
+    if (!ctx || !d_w || !d_out) return NSOF_EINVAL;
+    if (!n) return NSOF_OK;
+    hipLaunchKernelGGL(k_resistance, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_w, d_out, n,
+                       (float)(-std::log(ROFF / RON)));
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_read_w(nsof_accum* a, int which, float* out)
+{
+    if (!a || !out || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    NSOF_HIP(ctx, hipMemcpyAsync(out, a->w[which], a->npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_read_resistance(nsof_accum* a, int which, float* out)
+{
+    if (!a || !out || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    float* tmp = nullptr;
+    int rc = accum_alloc(ctx, (void**)&tmp, a->npx * sizeof(float));
+    if (rc) return rc;
+    rc = nsof_accum_resistance_dev(ctx, a->w[which], tmp, a->npx);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, tmp, a->npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = nsof_set_error(ctx, NSOF_EDEVICE, "copy failed: %s", hipGetErrorString(e));
+    }
+    hipFree(tmp);
+    return rc;
+}
+
+extern "C" int64_t nsof_accum_snapshot_count(const nsof_accum* a) { return a ? a->snap_count : 0; }
+
+extern "C" int nsof_accum_read_snapshots(nsof_accum* a, int which, float* out, int64_t max_count)
+{
+    if (!a || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    const int64_t n = a->snap_count < max_count ? a->snap_count : max_count;
+    if (n > 0) {
+        if (!out) return NSOF_EINVAL;
+        NSOF_HIP(ctx, hipMemcpyAsync(out, a->snap[which], (size_t)n * a->npx * sizeof(float), hipMemcpyDeviceToHost,
+                                     ctx->stream));
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (which == (a->split ? 1 : 0)) a->snap_count = 0;  // cleared after the last array has been read
+    return NSOF_OK;
+}
+
+extern "C" int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t slice_us, int64_t* idx, int64_t cap)
+{
+    if (!t || n <= 0 || slice_us <= 0) return 0;
+    const int64_t start = t[0], stop = t[n - 1] + slice_us;
+    int64_t nb = (stop - start + slice_us - 1) / slice_us;
+    if (nb < 0) nb = 0;
+    if (idx) {
+        int64_t pos = 0;
+        for (int64_t i = 0; i < nb && i < cap; i++) {
+            const int64_t b = start + i * slice_us;
+            while (pos < n && t[pos] < b) pos++;
+            idx[i] = pos;
+        }
+    }
+    return nb;
+}

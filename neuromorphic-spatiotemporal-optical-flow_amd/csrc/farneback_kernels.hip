@@ -1,0 +1,644 @@
+// Farneback dense optical flow: HIP kernels for gfx950 (CDNA4, wave64).
+//
+// Replaces the arithmetic the reference obtains from cv2.calcOpticalFlowFarneback
+// (call sites: /root/reference/optical_flow_seg.py:158,203,494 and the ob/prediction/yolo
+// twins).  Every kernel keeps the reference library's operation order and float/double
+// placement (see DESIGN.md "numerics contract"); this translation unit is compiled with
+// -ffp-contract=off so that a*b+c stays two roundings unless fma() is written explicitly.
+//
+// All kernels are HBM/L2-bound stencils: no MFMA.  Layouts: images [n][h][w] f32,
+// R and M planar [n][5][h][w] f32 (coalesced 256 B per wave per plane), flow [n][h][w][2].
+#include "nsof_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int floor_f(float v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+
+// resize(INTER_LINEAR) coordinate: f = (float)((d+0.5)*scale-0.5); s = floor(f); a = f-s.
+__device__ __forceinline__ void lin_coord_x(int d, double scale, int slen, int& s, float& a)
+{
+    float f = (float)((d + 0.5) * scale - 0.5);
+    s = floor_f(f);
+    a = f - s;
+    if (s < 0) { s = 0; a = 0.f; }
+    if (s >= slen - 1) { s = slen - 1; a = 0.f; }
+}
+__device__ __forceinline__ void lin_coord_y(int d, double scale, int& s, float& a)
+{
+    float f = (float)((d + 0.5) * scale - 0.5);
+    s = floor_f(f);
+    a = f - s;
+}
+
+// ---------------------------------------------------------------------------------------
+// Pyramid level preparation: u8 -> f32, separable Gaussian (sepFilter2D order), bilinear
+// resample of the blurred FULL-RES image to (wk, hk).
+// ---------------------------------------------------------------------------------------
+
+// Row filter at an (unreflected) column c of one row, ordering per kernel size.
+template <typename LoadF>
+__device__ __forceinline__ float row_filter(const nsof_blur_taps& t, int c, LoadF ld)
+{
+    const int ks = t.ksize, r = ks >> 1;
+    if (ks == 3) return ld(c) * t.k[1] + (ld(c - 1) + ld(c + 1)) * t.k[2];
+    if (ks == 5) return ld(c) * t.k[2] + (ld(c - 1) + ld(c + 1)) * t.k[3] + (ld(c - 2) + ld(c + 2)) * t.k[4];
+    float s = t.k[0] * ld(c - r);
+    for (int j = 1; j < ks; j++) s += t.k[j] * ld(c - r + j);
+    return s;
+}
+// Column filter at (unreflected) row rr given an accessor of row-filtered values.
+template <typename LoadF>
+__device__ __forceinline__ float col_filter(const nsof_blur_taps& t, int rr, LoadF hv)
+{
+    const int ks = t.ksize, r = ks >> 1;
+    if (ks == 3) return (hv(rr - 1) + hv(rr + 1)) * t.k[2] + hv(rr) * t.k[1];
+    float s = t.k[r] * hv(rr);
+    for (int j = 1; j <= r; j++) s += t.k[r + j] * (hv(rr + j) + hv(rr - j));
+    return s;
+}
+
+// Same-size level (k = 0): one thread per pixel, no resample.
+__global__ __launch_bounds__(256) void k_prep_same(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                    ptrdiff_t img_stride, int W, int H, nsof_blur_taps t,
+                                                    float* __restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    auto hv = [&](int rr) {
+        const uint8_t* rowp = img + (ptrdiff_t)reflect101(rr, H) * row_stride;
+        return row_filter(t, x, [&](int c) { return (float)rowp[reflect101(c, W)]; });
+    };
+    out[((size_t)blockIdx.z * H + y) * W + x] = col_filter(t, y, hv);
+}
+
+// Resampled level, generic fallback: one thread per destination pixel, no data sharing.
+__global__ __launch_bounds__(256) void k_prep_naive(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                     ptrdiff_t img_stride, int W, int H, int wk, int hk,
+                                                     double scale_x, double scale_y, nsof_blur_taps t,
+                                                     float* __restrict__ out)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= wk || dy >= hk) return;
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    int sx, sy;
+    float a1, b1;
+    lin_coord_x(dx, scale_x, W, sx, a1);
+    lin_coord_y(dy, scale_y, sy, b1);
+    const float a0 = 1.f - a1, b0 = 1.f - b1;
+    const int c0 = sx, c1 = min(sx + 1, W - 1);
+    const int r0 = clampi(sy, 0, H - 1), r1 = clampi(sy + 1, 0, H - 1);
+    auto blur = [&](int rr, int cc) {
+        auto hv = [&](int q) {
+            const uint8_t* rowp = img + (ptrdiff_t)reflect101(q, H) * row_stride;
+            return row_filter(t, cc, [&](int c) { return (float)rowp[reflect101(c, W)]; });
+        };
+        return col_filter(t, rr, hv);
+    };
+    const float t0 = blur(r0, c0) * a0 + blur(r0, c1) * a1;
+    const float t1 = blur(r1, c0) * a0 + blur(r1, c1) * a1;
+    out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+}
+
+// Resampled level, LDS-tiled: a 32x8 destination tile per 256-thread block.
+//   phase 1: source footprint (with blur halo, borders reflected) -> LDS as u8
+//   phase 2: row filter only at the 2 source columns each destination column samples
+//   phase 3: column filter only at the 2 source rows each destination row samples
+//   phase 4: bilinear blend (horizontal first, then vertical, as resize does)
+constexpr int PREP_TW = 32, PREP_TH = 8;
+__global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                     ptrdiff_t img_stride, int W, int H, int wk, int hk,
+                                                     double scale_x, double scale_y, int rw_cap, int rh_cap,
+                                                     nsof_blur_taps t, float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sH = reinterpret_cast<float*>(smem);                 // [rh_cap][2*TW]
+    float* sB = sH + (size_t)rh_cap * (2 * PREP_TW);            // [2*TH][2*TW]
+    unsigned char* sU = reinterpret_cast<unsigned char*>(sB + 2 * PREP_TH * 2 * PREP_TW);  // [rh_cap][rw_cap]
+    __shared__ int s_c[2 * PREP_TW];   // absolute source column per (dst col, 0/1)
+    __shared__ int s_r[2 * PREP_TH];   // absolute source row per (dst row, 0/1)
+    __shared__ float s_a[PREP_TW], s_b[PREP_TH];
+
+    const int tid = threadIdx.x;
+    const int r = t.ksize >> 1;
+    const int dx0 = blockIdx.x * PREP_TW, dy0 = blockIdx.y * PREP_TH;
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+
+    if (tid < PREP_TW) {
+        int dx = min(dx0 + tid, wk - 1), sx;
+        float a;
+        lin_coord_x(dx, scale_x, W, sx, a);
+        s_c[2 * tid] = sx;
+        s_c[2 * tid + 1] = min(sx + 1, W - 1);
+        s_a[tid] = a;
+    } else if (tid >= 64 && tid < 64 + PREP_TH) {
+        int i = tid - 64, dy = min(dy0 + i, hk - 1), sy;
+        float b;
+        lin_coord_y(dy, scale_y, sy, b);
+        s_r[2 * i] = clampi(sy, 0, H - 1);
+        s_r[2 * i + 1] = clampi(sy + 1, 0, H - 1);
+        s_b[i] = b;
+    }
+    __syncthreads();
+    // coordinates are monotone in dx/dy, so the footprint is [first .. last]
+    const int C0 = s_c[0] - r, RW = s_c[2 * PREP_TW - 1] + r - C0 + 1;
+    const int R0 = s_r[0] - r, RH = s_r[2 * PREP_TH - 1] + r - R0 + 1;
+    // host sized rw_cap/rh_cap from the same arithmetic; RW<=rw_cap, RH<=rh_cap always hold
+
+    for (int i = tid; i < RH * RW; i += 256) {
+        int rr = i / RW, cc = i - rr * RW;
+        sU[rr * rw_cap + cc] = img[(ptrdiff_t)reflect101(R0 + rr, H) * row_stride + reflect101(C0 + cc, W)];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * 2 * PREP_TW; i += 256) {
+        int rr = i / (2 * PREP_TW), j = i - rr * (2 * PREP_TW);
+        const unsigned char* rowp = sU + rr * rw_cap - C0;
+        sH[rr * (2 * PREP_TW) + j] = row_filter(t, s_c[j], [&](int c) { return (float)rowp[c]; });
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * PREP_TH * 2 * PREP_TW; i += 256) {
+        int q = i / (2 * PREP_TW), j = i - q * (2 * PREP_TW);
+        sB[i] = col_filter(t, s_r[q] - R0, [&](int rr) { return sH[rr * (2 * PREP_TW) + j]; });
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    const int dx = dx0 + tx, dy = dy0 + ty;
+    if (dx < wk && dy < hk) {
+        const float a1 = s_a[tx], a0 = 1.f - a1, b1 = s_b[ty], b0 = 1.f - b1;
+        const float* B0 = sB + (2 * ty) * (2 * PREP_TW) + 2 * tx;
+        const float* B1 = B0 + 2 * PREP_TW;
+        const float t0 = B0[0] * a0 + B0[1] * a1;
+        const float t1 = B1[0] * a0 + B1[1] * a1;
+        out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Polynomial expansion (FarnebackPolyExp).  24 B/px algorithmic: 4 read + 5 x 4 written.
+//
+// "Strip walker": a 256-thread block owns 256 image columns (SW output columns + NP halo on
+// each side) and walks down a row segment four rows per step.
+//   vertical pass   thread <-> column; the 2N+1 input rows of the column live in a register
+//                   window (one coalesced dword load per thread per new row, prefetched one
+//                   step ahead); r0/r1/r2 (float accumulation) go to LDS.
+//   horizontal pass wave <-> row, lane <-> 4 adjacent pixels; taps come from LDS as
+//                   ds_read_b128 and are reused across the 4 pixels in registers; the six
+//                   moments accumulate in double exactly as the reference library does
+//                   (b1,b4: double products -- exact, so written as fma; b2,b3,b5,b6: float
+//                   products widened afterwards); 5 coalesced float4 stores per lane.
+// ---------------------------------------------------------------------------------------
+template <int N>
+struct PolyGeom {
+    static constexpr int NP = (N + 3) / 4 * 4;  // halo padded so LDS vectors stay 16-B aligned
+    static constexpr int SW = 256 - 2 * NP;     // output columns per block
+    static constexpr int NV = (2 * NP + 4) / 4; // float4 per lane per moment row
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, float* __restrict__ R, int W, int H,
+                                                  int seg_rows, nsof_poly_taps tp)
+{
+    using G = PolyGeom<N>;
+    __shared__ __attribute__((aligned(16))) float sr[2][3][4][256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * G::SW;
+    const int ys = blockIdx.y * seg_rows, ye = min(ys + seg_rows, H);
+    const size_t plane = (size_t)W * H;
+    const float* I = img + (size_t)blockIdx.z * plane;
+    float* Rz = R + (size_t)blockIdx.z * 5 * plane;
+    const int xc = clampi(x0 - G::NP + tid, 0, W - 1);
+    const float* Ic = I + xc;
+
+    // register window: win[j] = I[clamp(y - N + j)][xc]
+    float win[2 * N + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * N; j++) win[j] = Ic[(size_t)clampi(ys - N + j, 0, H - 1) * W];
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) pre[q] = Ic[(size_t)clampi(ys + 1 + N + q, 0, H - 1) * W];
+
+    int buf = 0;
+    for (int y = ys; y < ye; y += 4, buf ^= 1) {
+        float nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = Ic[(size_t)clampi(y + 5 + N + q, 0, H - 1) * W];
+
+        // ---- vertical pass: 4 rows for this thread's column
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float t0 = win[N] * tp.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const float a = win[N - k], b = win[N + k];
+                float p = a + b;
+                t0 = t0 + tp.g[k] * p;
+                t2 = t2 + tp.xxg[k] * p;
+                p = b - a;
+                t1 = t1 + tp.xg[k] * p;
+            }
+            sr[buf][0][q][tid] = t0;
+            sr[buf][1][q][tid] = t1;
+            sr[buf][2][q][tid] = t2;
+#pragma unroll
+            for (int j = 0; j < 2 * N; j++) win[j] = win[j + 1];
+            win[2 * N] = pre[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) pre[q] = nxt[q];
+        __syncthreads();
+
+        // ---- horizontal pass: wave <-> row, lane <-> 4 pixels
+        const int yo = y + wave;
+        const int xo = x0 + 4 * lane;
+        if (4 * lane < G::SW && yo < ye && xo < W) {
+            double b1[4], b2[4], b3[4], b4[4], b5[4], b6[4];
+            {
+                float v[4 * G::NV];
+                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][0][wave][4 * lane]);
+#pragma unroll
+                for (int i = 0; i < G::NV; i++) {
+                    float4 f = p4[i];
+                    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int c = G::NP + p;
+                    double a1 = (double)(v[c] * tp.g[0]), a2 = 0, a4 = 0;
+#pragma unroll
+                    for (int k = 1; k <= N; k++) {
+                        const float hi = v[c + k], lo = v[c - k];
+                        const double tg = (double)(hi + lo);
+                        a1 = fma(tg, tp.dg[k], a1);     // product of two float-valued doubles is exact
+                        a4 = fma(tg, tp.dxxg[k], a4);
+                        a2 += (double)((hi - lo) * tp.xg[k]);
+                    }
+                    b1[p] = a1; b2[p] = a2; b4[p] = a4;
+                }
+            }
+            {
+                float v[4 * G::NV];
+                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][1][wave][4 * lane]);
+#pragma unroll
+                for (int i = 0; i < G::NV; i++) {
+                    float4 f = p4[i];
+                    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int c = G::NP + p;
+                    double a3 = (double)(v[c] * tp.g[0]), a6 = 0;
+#pragma unroll
+                    for (int k = 1; k <= N; k++) {
+                        const float hi = v[c + k], lo = v[c - k];
+                        a3 += (double)((hi + lo) * tp.g[k]);
+                        a6 += (double)((hi - lo) * tp.xg[k]);
+                    }
+                    b3[p] = a3; b6[p] = a6;
+                }
+            }
+            {
+                float v[4 * G::NV];
+                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][2][wave][4 * lane]);
+#pragma unroll
+                for (int i = 0; i < G::NV; i++) {
+                    float4 f = p4[i];
+                    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int c = G::NP + p;
+                    double a5 = (double)(v[c] * tp.g[0]);
+#pragma unroll
+                    for (int k = 1; k <= N; k++) a5 += (double)((v[c + k] + v[c - k]) * tp.g[k]);
+                    b5[p] = a5;
+                }
+            }
+            float o[5][4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                o[0][p] = (float)(b3[p] * tp.ig11);
+                o[1][p] = (float)(b2[p] * tp.ig11);
+                o[2][p] = (float)(b1[p] * tp.ig03 + b5[p] * tp.ig33);
+                o[3][p] = (float)(b1[p] * tp.ig03 + b4[p] * tp.ig33);
+                o[4][p] = (float)(b6[p] * tp.ig55);
+            }
+            float* dst = Rz + (size_t)yo * W + xo;
+            if ((W & 3) == 0) {
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+                    *reinterpret_cast<float4*>(dst + c * plane) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; c++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (xo + p < W) dst[c * plane + p] = o[c][p];
+            }
+        }
+        // no second barrier: the next step writes the other LDS buffer
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// FarnebackUpdateMatrices: one thread per pixel.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R0b, const float* __restrict__ R1b,
+                                                          size_t pair_stride, const float* __restrict__ flow,
+                                                          int W, int H, float* __restrict__ M)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t plane = (size_t)W * H;
+    const float* R0 = R0b + (size_t)blockIdx.z * pair_stride;
+    const float* R1 = R1b + (size_t)blockIdx.z * pair_stride;
+    const size_t pix = (size_t)y * W + x;
+    const float2 d = reinterpret_cast<const float2*>(flow)[(size_t)blockIdx.z * plane + pix];
+    const float dx = d.x, dy = d.y;
+    float fx = x + dx, fy = y + dy;
+    const int x1 = floor_f(fx), y1 = floor_f(fy);
+    fx -= x1;
+    fy -= y1;
+    float r2, r3, r4, r5, r6;
+    if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float* p = R1 + (size_t)y1 * W + x1;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1];
+        r4 = (R0[2 * plane + pix] + r4) * 0.5f;
+        r5 = (R0[3 * plane + pix] + r5) * 0.5f;
+        r6 = (R0[4 * plane + pix] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * plane + pix];
+        r5 = R0[3 * plane + pix];
+        r6 = R0[4 * plane + pix] * 0.5f;
+    }
+    r2 = (R0[pix] - r2) * 0.5f;
+    r3 = (R0[plane + pix] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10)) {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        auto bw = [&](int i) { return i == 0 || i == 1 ? border[0] : border[2]; };
+        const float scale = (x < 5 ? bw(x) : 1.f) * (x >= W - 5 ? bw(W - x - 1) : 1.f) * (y < 5 ? bw(y) : 1.f) *
+                            (y >= H - 5 ? bw(H - y - 1) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    float* Mz = M + (size_t)blockIdx.z * 5 * plane + pix;
+    Mz[0] = r4 * r4 + r6 * r6;
+    Mz[plane] = (r4 + r5) * r6;
+    Mz[2 * plane] = r5 * r5 + r6 * r6;
+    Mz[3 * plane] = r4 * r2 + r6 * r3;
+    Mz[4 * plane] = r6 * r2 + r5 * r3;
+}
+
+// ---------------------------------------------------------------------------------------
+// FarnebackUpdateFlow_Blur: (2m+1)^2 box sums of the 5 planes of M + per-pixel 2x2 solve.
+//
+// Strip walker over the full image height (the column sums are a running sum from row 0:
+// each row adds double(float(M[y+m] - M[y-m-1])) -- the float rounding of the difference is
+// part of the reference arithmetic and is reproduced).  thread <-> column keeps the 5
+// column sums in registers as doubles; 4 rows per step go to LDS; wave <-> row, lane <-> 4
+// pixels forms the row sums (first pixel direct, then sliding) and solves.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur_solve(const float* __restrict__ M, int W, int H, int m, int block_size,
+                                                     float* __restrict__ flow)
+{
+    __shared__ double sv[4][5][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int SW = (256 - 2 * m) & ~3;  // multiple of 4: every lane owns 4 whole pixels
+    const int x0 = blockIdx.x * SW;
+    const size_t plane = (size_t)W * H;
+    const float* Mz = M + (size_t)blockIdx.z * 5 * plane;
+    float2* fz = reinterpret_cast<float2*>(flow) + (size_t)blockIdx.z * plane;
+    const int xc = clampi(x0 - m + tid, 0, W - 1);
+    const float* Mc = Mz + xc;
+    const double scale = 1. / (block_size * block_size);
+
+    double vs[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        vs[c] = (double)(Mc[c * plane] * (float)(m + 2));  // float product, as "srow0[x]*(m+2)"
+        for (int y = 1; y < m; y++) vs[c] += (double)Mc[c * plane + (size_t)min(y, H - 1) * W];
+    }
+    float pa[4][5], pb[4][5];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            pa[q][c] = Mc[c * plane + (size_t)min(q + m, H - 1) * W];
+            pb[q][c] = Mc[c * plane + (size_t)max(q - m - 1, 0) * W];
+        }
+
+    for (int y = 0; y < H; y += 4) {
+        float na[4][5], nb[4][5];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                na[q][c] = Mc[c * plane + (size_t)min(y + 4 + q + m, H - 1) * W];
+                nb[q][c] = Mc[c * plane + (size_t)max(y + 4 + q - m - 1, 0) * W];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float d = pa[q][c] - pb[q][c];
+                vs[c] += (double)d;
+                sv[q][c][tid] = vs[c];
+            }
+        __syncthreads();
+        const int yo = y + wave, xo = x0 + 4 * lane;
+        if (4 * lane < SW && yo < H && xo < W) {
+            double g[5];
+            float2 o[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                if (p == 0) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        double s = 0;
+                        for (int j = 0; j <= 2 * m; j++) s += sv[wave][c][4 * lane + j];
+                        g[c] = s;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 5; c++)
+                        g[c] += sv[wave][c][4 * lane + p + 2 * m] - sv[wave][c][4 * lane + p - 1];
+                }
+                const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+                const double h1 = g[3] * scale, h2 = g[4] * scale;
+                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
+                o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+            float2* dst = fz + (size_t)yo * W + xo;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (4 * lane + p < SW && xo + p < W) dst[p] = o[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                pa[q][c] = na[q][c];
+                pb[q][c] = nb[q][c];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Coarse-to-fine flow resample: resize(prevFlow, INTER_LINEAR) then "flow *= 1/pyr_scale".
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_upsample(const float* __restrict__ src, int sw, int sh,
+                                                        float* __restrict__ dst, int dw, int dh, double scale_x,
+                                                        double scale_y, float mul)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    int sx, sy;
+    float a1, b1;
+    lin_coord_x(dx, scale_x, sw, sx, a1);
+    lin_coord_y(dy, scale_y, sy, b1);
+    const float a0 = 1.f - a1, b0 = 1.f - b1;
+    const int c1 = min(sx + 1, sw - 1);
+    const int r0 = clampi(sy, 0, sh - 1), r1 = clampi(sy + 1, 0, sh - 1);
+    const float2* S = reinterpret_cast<const float2*>(src) + (size_t)blockIdx.z * sw * sh;
+    const float2 p00 = S[(size_t)r0 * sw + sx], p01 = S[(size_t)r0 * sw + c1];
+    const float2 p10 = S[(size_t)r1 * sw + sx], p11 = S[(size_t)r1 * sw + c1];
+    float2 o;
+    {
+        const float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
+        o.x = (t0 * b0 + t1 * b1) * mul;
+    }
+    {
+        const float t0 = p00.y * a0 + p01.y * a1, t1 = p10.y * a0 + p11.y * a1;
+        o.y = (t0 * b0 + t1 * b1) * mul;
+    }
+    reinterpret_cast<float2*>(dst)[((size_t)blockIdx.z * dh + dy) * dw + dx] = o;
+}
+
+template <int N>
+void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R)
+{
+    using G = PolyGeom<N>;
+    const int strips = (W + G::SW - 1) / G::SW;
+    // segment the height so that the grid has >= ~2048 blocks, but keep segments >= 64 rows
+    int segs = 1;
+    while (segs < 64 && (long long)strips * n_img * segs < 2048 && (H / (segs * 2)) >= 64) segs *= 2;
+    int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
+    segs = (H + seg_rows - 1) / seg_rows;
+    dim3 grid(strips, segs, n_img);
+    hipLaunchKernelGGL(k_polyexp<N>, grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps);
+}
+
+}  // namespace
+
+// =========================================================================================
+// launchers
+// =========================================================================================
+int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
+                     int H, int wk, int hk, const nsof_blur_taps& taps, float* out)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_PREP);
+    if (wk == W && hk == H) {
+        dim3 grid((W + 63) / 64, (H + 3) / 4, n_img);
+        hipLaunchKernelGGL(k_prep_same, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, taps, out);
+    } else {
+        const double scale_x = 1. / ((double)wk / W), scale_y = 1. / ((double)hk / H);
+        const int r = taps.ksize / 2;
+        const int rw_cap = ((int)ceil(PREP_TW * scale_x) + 2 * r + 4 + 3) / 4 * 4;
+        const int rh_cap = (int)ceil(PREP_TH * scale_y) + 2 * r + 4;
+        const size_t smem = sizeof(float) * ((size_t)rh_cap * 2 * PREP_TW + 2 * PREP_TH * 2 * PREP_TW) +
+                            (size_t)rh_cap * rw_cap;
+        if (smem <= 60 * 1024 && scale_x >= 1.0 && scale_y >= 1.0) {
+            dim3 grid((wk + PREP_TW - 1) / PREP_TW, (hk + PREP_TH - 1) / PREP_TH, n_img);
+            hipLaunchKernelGGL(k_prep_tiled, grid, dim3(256), smem, ctx->stream, src, row_stride, img_stride, W, H, wk,
+                               hk, scale_x, scale_y, rw_cap, rh_cap, taps, out);
+        } else {
+            dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
+            hipLaunchKernelGGL(k_prep_naive, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk,
+                               hk, scale_x, scale_y, taps, out);
+        }
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_POLYEXP);
+    switch (taps.n) {
+        case 1: launch_polyexp_n<1>(ctx, n_img, img, W, H, taps, R); break;
+        case 2: launch_polyexp_n<2>(ctx, n_img, img, W, H, taps, R); break;
+        case 3: launch_polyexp_n<3>(ctx, n_img, img, W, H, taps, R); break;
+        case 4: launch_polyexp_n<4>(ctx, n_img, img, W, H, taps, R); break;
+        case 5: launch_polyexp_n<5>(ctx, n_img, img, W, H, taps, R); break;
+        case 6: launch_polyexp_n<6>(ctx, n_img, img, W, H, taps, R); break;
+        case 7: launch_polyexp_n<7>(ctx, n_img, img, W, H, taps, R); break;
+        case 8: launch_polyexp_n<8>(ctx, n_img, img, W, H, taps, R); break;
+        case 9: launch_polyexp_n<9>(ctx, n_img, img, W, H, taps, R); break;
+        case 10: launch_polyexp_n<10>(ctx, n_img, img, W, H, taps, R); break;
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "poly_n=%d outside 1..%d", taps.n, NSOF_MAX_POLY_N);
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_update_matrices(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                                const float* flow, int W, int H, float* M)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_UPDMAT);
+    dim3 grid((W + 63) / 64, (H + 3) / 4, n_pairs);
+    hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, ctx->stream, R0, R1, pair_stride, flow, W, H, M);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_blur_solve(nsof_ctx* ctx, int n_pairs, const float* M, int W, int H, int winsize, float* flow)
+{
+    const int m = winsize / 2;
+    if (m > 96) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "winsize=%d too large (max 193)", winsize);
+    nsof_prof_scope ps(ctx, NSOF_K_BLUR);
+    const int SW = (256 - 2 * m) & ~3;
+    dim3 grid((W + SW - 1) / SW, 1, n_pairs);
+    hipLaunchKernelGGL(k_blur_solve, grid, dim3(256), 0, ctx->stream, M, W, H, m, winsize, flow);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw, int dh,
+                              float mul)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_UPSAMPLE);
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_pairs);
+    hipLaunchKernelGGL(k_flow_upsample, grid, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x, scale_y,
+                       mul);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}

@@ -1,0 +1,469 @@
+// libnsof.so host side: context, error channel, profiling hooks, Farneback level driver.
+// The level loop mirrors the driver of the reference's flow backend
+// (cv2.calcOpticalFlowFarneback, called at /root/reference/optical_flow_seg.py:203):
+// coarsest level first, every level resampled from the blurred FULL-RES frame.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "nsof_internal.h"
+
+static char g_create_err[512] = "";
+
+int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...)
+{
+    char* dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int nsof_ws_reserve(nsof_ctx* ctx, void** buf, size_t* cur, size_t need)
+{
+    if (*cur >= need) return NSOF_OK;
+    if (*buf) {
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NSOF_HIP(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *cur = 0;
+    }
+    hipError_t e = hipMalloc(buf, need);
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        return nsof_set_error(ctx, NSOF_ENOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    }
+    *cur = need;
+    return NSOF_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------
+nsof_prof_scope::nsof_prof_scope(nsof_ctx* c, int k) : ctx(c), id(k), on((c->prof_mask >> k) & 1u)
+{
+    if (!on) return;
+    nsof_prof_slot& s = ctx->prof[id];
+    if (s.used == s.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        s.start.push_back(a);
+        s.stop.push_back(b);
+    }
+    hipEventRecord(s.start[s.used], ctx->stream);
+}
+nsof_prof_scope::~nsof_prof_scope()
+{
+    if (!on) return;
+    nsof_prof_slot& s = ctx->prof[id];
+    hipEventRecord(s.stop[s.used], ctx->stream);
+    s.used++;
+}
+
+extern "C" int nsof_prof_enable(nsof_ctx* ctx, unsigned mask)
+{
+    if (!ctx) return NSOF_EINVAL;
+    ctx->prof_mask = mask & ((1u << NSOF_K_COUNT) - 1);
+    return NSOF_OK;
+}
+
+extern "C" int nsof_prof_collect(nsof_ctx* ctx, int id, double* total_ms, long long* launches)
+{
+    if (!ctx || id < 0 || id >= NSOF_K_COUNT) return NSOF_EINVAL;
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    nsof_prof_slot& s = ctx->prof[id];
+    for (size_t i = 0; i < s.used; i++) {
+        float ms = 0;
+        NSOF_HIP(ctx, hipEventElapsedTime(&ms, s.start[i], s.stop[i]));
+        s.acc_ms += ms;
+        s.acc_launches++;
+    }
+    s.used = 0;
+    if (total_ms) *total_ms = s.acc_ms;
+    if (launches) *launches = s.acc_launches;
+    s.acc_ms = 0;
+    s.acc_launches = 0;
+    return NSOF_OK;
+}
+
+extern "C" const char* nsof_kernel_name(int id)
+{
+    static const char* names[NSOF_K_COUNT] = {"prep", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
+                                              "accum_update"};
+    return (id >= 0 && id < NSOF_K_COUNT) ? names[id] : "?";
+}
+
+// ---- context -----------------------------------------------------------------------------
+extern "C" int nsof_abi_version(void) { return NSOF_ABI_VERSION; }
+
+extern "C" int nsof_create(int device, nsof_ctx** out)
+{
+    if (!out) return NSOF_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return nsof_set_error(nullptr, NSOF_EDEVICE, "no HIP device available (%s); libnsof has no CPU fallback",
+                              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return nsof_set_error(nullptr, NSOF_EINVAL, "device %d out of range (0..%d)", device, count - 1);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return nsof_set_error(nullptr, NSOF_EDEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return nsof_set_error(nullptr, NSOF_EDEVICE, "device %d is %s; libnsof is built for gfx950 only", device,
+                              prop.gcnArchName);
+    if ((e = hipSetDevice(device)) != hipSuccess)
+        return nsof_set_error(nullptr, NSOF_EDEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    nsof_ctx* ctx = new (std::nothrow) nsof_ctx();
+    if (!ctx) return nsof_set_error(nullptr, NSOF_ENOMEM, "out of host memory");
+    ctx->device = device;
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete ctx;
+        return nsof_set_error(nullptr, NSOF_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return NSOF_OK;
+}
+
+extern "C" void nsof_destroy(nsof_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->prof) {
+        for (auto ev : s.start) hipEventDestroy(ev);
+        for (auto ev : s.stop) hipEventDestroy(ev);
+    }
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char* nsof_last_error(const nsof_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int nsof_set_stream(nsof_ctx* ctx, void* s)
+{
+    if (!ctx) return NSOF_EINVAL;
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return NSOF_OK;
+}
+
+extern "C" int nsof_synchronize(nsof_ctx* ctx)
+{
+    if (!ctx) return NSOF_EINVAL;
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NSOF_OK;
+}
+
+// ---- filter taps (host, double precision as the reference library computes them) -----------
+static int round_half_even(double v) { return (int)lrint(v); }
+
+int nsof_host_blur_taps(int ksize, double sigma, nsof_blur_taps* out)
+{
+    if (ksize < 1 || (ksize & 1) == 0 || ksize > NSOF_MAX_BLUR_TAPS - 1) return NSOF_EUNSUPPORTED;
+    out->ksize = ksize;
+    memset(out->k, 0, sizeof(out->k));
+    if (sigma <= 0 && ksize <= 9) {  // fixed small tables
+        static const double t1[] = {1.};
+        static const double t3[] = {0.25, 0.5, 0.25};
+        static const double t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+        static const double t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+        static const double t9[] = {4. / 256, 13. / 256, 30. / 256, 51. / 256, 60. / 256, 51. / 256, 30. / 256, 13. / 256, 4. / 256};
+        const double* t = ksize == 1 ? t1 : ksize == 3 ? t3 : ksize == 5 ? t5 : ksize == 7 ? t7 : t9;
+        for (int i = 0; i < ksize; i++) out->k[i] = (float)t[i];
+        return NSOF_OK;
+    }
+    const double sg = sigma > 0 ? sigma : ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2 = -0.125 / (sg * sg);
+    const int h = (ksize - 1) / 2;
+    double v[NSOF_MAX_BLUR_TAPS], sum = 0;
+    for (int i = 0, x = 1 - ksize; i < h; i++, x += 2) {
+        v[i] = std::exp((double)(x * x) * scale2);
+        sum += v[i];
+    }
+    sum = sum * 2.0 + 1.0;
+    const double inv = 1.0 / sum;
+    for (int i = 0; i < h; i++) out->k[i] = out->k[ksize - 1 - i] = (float)(v[i] * inv);
+    out->k[h] = (float)inv;
+    return NSOF_OK;
+}
+
+static bool chol_inv6(const double A[6][6], double inv[6][6])
+{
+    double L[6][6] = {{0}};
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = A[i][j];
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (s <= 0) return false;
+                L[i][i] = std::sqrt(s);
+            } else
+                L[i][j] = s / L[j][j];
+        }
+    for (int c = 0; c < 6; c++) {
+        double y[6], x[6];
+        for (int i = 0; i < 6; i++) {
+            double s = (i == c) ? 1. : 0.;
+            for (int k = 0; k < i; k++) s -= L[i][k] * y[k];
+            y[i] = s / L[i][i];
+        }
+        for (int i = 5; i >= 0; i--) {
+            double s = y[i];
+            for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k];
+            x[i] = s / L[i][i];
+        }
+        for (int i = 0; i < 6; i++) inv[i][c] = x[i];
+    }
+    return true;
+}
+
+int nsof_host_poly_taps(int n, double sigma, nsof_poly_taps* out)
+{
+    if (n < 1 || n > NSOF_MAX_POLY_N) return NSOF_EUNSUPPORTED;
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    float g[2 * NSOF_MAX_POLY_N + 1], xg[2 * NSOF_MAX_POLY_N + 1], xxg[2 * NSOF_MAX_POLY_N + 1];
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x + n] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += g[x + n];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x + n] = (float)(g[x + n] * s);
+        xg[x + n] = (float)(x * g[x + n]);
+        xxg[x + n] = (float)(x * x * g[x + n]);
+    }
+    double G[6][6] = {{0}}, inv[6][6];
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y + n] * g[x + n];
+            G[1][1] += g[y + n] * g[x + n] * x * x;
+            G[3][3] += g[y + n] * g[x + n] * x * x * x * x;
+            G[5][5] += g[y + n] * g[x + n] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    if (!chol_inv6(G, inv)) return NSOF_EINVAL;
+    memset(out, 0, sizeof(*out));
+    out->n = n;
+    for (int k = 0; k <= n; k++) {
+        out->g[k] = g[n + k];
+        out->xg[k] = xg[n + k];
+        out->xxg[k] = xxg[n + k];
+        out->dg[k] = (double)g[n + k];
+        out->dxxg[k] = (double)xxg[n + k];
+    }
+    out->ig11 = inv[1][1];
+    out->ig03 = inv[0][3];
+    out->ig33 = inv[3][3];
+    out->ig55 = inv[5][5];
+    return NSOF_OK;
+}
+
+// ---- level geometry ------------------------------------------------------------------------
+extern "C" int nsof_farneback_effective_levels(int width, int height, double pyr_scale, int levels)
+{
+    int k;
+    double scale = 1;
+    for (k = 0; k < levels; k++) {
+        scale *= pyr_scale;
+        if (width * scale < 32 || height * scale < 32) break;
+    }
+    return k;
+}
+
+extern "C" int nsof_farneback_level_size(int width, int height, double pyr_scale, int level, int* lw, int* lh,
+                                          int* ksize, double* sigma)
+{
+    if (width < 1 || height < 1 || level < 0 || !(pyr_scale > 0) || !(pyr_scale < 1)) return NSOF_EINVAL;
+    double scale = 1;
+    for (int i = 0; i < level; i++) scale *= pyr_scale;
+    const double sg = (1. / scale - 1) * 0.5;
+    int sz = round_half_even(sg * 5) | 1;
+    if (sz < 3) sz = 3;
+    if (lw) *lw = round_half_even(width * scale);
+    if (lh) *lh = round_half_even(height * scale);
+    if (ksize) *ksize = sz;
+    if (sigma) *sigma = sg;
+    return NSOF_OK;
+}
+
+static int check_params(nsof_ctx* ctx, int width, int height, double pyr_scale, int levels, int winsize,
+                        int iterations, int poly_n, int flags)
+{
+    if (width < 1 || height < 1) return nsof_set_error(ctx, NSOF_ESHAPE, "empty image %dx%d", width, height);
+    if (!(pyr_scale > 0) || !(pyr_scale < 1))
+        return nsof_set_error(ctx, NSOF_EINVAL, "pyr_scale=%g must be in (0,1)", pyr_scale);
+    if (winsize == 1)  // upstream's running sums are ill-formed for a 1x1 window (m = 0); never used by the reference
+        return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "winsize=1 is not supported");
+    if (levels < 0 || winsize < 1 || iterations < 0)
+        return nsof_set_error(ctx, NSOF_EINVAL, "levels=%d winsize=%d iterations=%d invalid", levels, winsize,
+                              iterations);
+    if (poly_n < 1 || poly_n > NSOF_MAX_POLY_N)
+        return nsof_set_error(ctx, poly_n < 1 ? NSOF_EINVAL : NSOF_EUNSUPPORTED, "poly_n=%d outside 1..%d", poly_n,
+                              NSOF_MAX_POLY_N);
+    if (flags != 0)
+        return nsof_set_error(ctx, NSOF_EUNSUPPORTED,
+                              "flags=%d: OPTFLOW_USE_INITIAL_FLOW / OPTFLOW_FARNEBACK_GAUSSIAN are not implemented "
+                              "(the reference always passes flags=0)", flags);
+    return NSOF_OK;
+}
+
+// ---- stage entry points ---------------------------------------------------------------------
+extern "C" int nsof_stage_pyr_level(nsof_ctx* ctx, int n_img, const uint8_t* d_src, ptrdiff_t row_stride,
+                                    ptrdiff_t img_stride, int width, int height, double pyr_scale, int level,
+                                    float* d_out)
+{
+    if (!ctx || !d_src || !d_out || n_img < 1) return NSOF_EINVAL;
+    int wk, hk, ks;
+    double sg;
+    int rc = nsof_farneback_level_size(width, height, pyr_scale, level, &wk, &hk, &ks, &sg);
+    if (rc) return nsof_set_error(ctx, rc, "bad level geometry");
+    nsof_blur_taps taps;
+    if ((rc = nsof_host_blur_taps(ks, sg, &taps)))
+        return nsof_set_error(ctx, rc, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
+    return nsof_launch_prep(ctx, n_img, d_src, row_stride, img_stride, width, height, wk, hk, taps, d_out);
+}
+
+extern "C" int nsof_stage_polyexp(nsof_ctx* ctx, int n_img, const float* d_img, int width, int height, int poly_n,
+                                  double poly_sigma, float* d_R)
+{
+    if (!ctx || !d_img || !d_R || n_img < 1 || width < 1 || height < 1) return NSOF_EINVAL;
+    nsof_poly_taps taps;
+    int rc = nsof_host_poly_taps(poly_n, poly_sigma, &taps);
+    if (rc) return nsof_set_error(ctx, rc, "poly_n=%d unsupported", poly_n);
+    return nsof_launch_polyexp(ctx, n_img, d_img, width, height, taps, d_R);
+}
+
+extern "C" int nsof_stage_update_matrices(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_flow,
+                                          int width, int height, float* d_M)
+{
+    if (!ctx || !d_R || !d_flow || !d_M || n_pairs < 1 || width < 1 || height < 1) return NSOF_EINVAL;
+    const size_t plane = (size_t)width * height;
+    return nsof_launch_update_matrices(ctx, n_pairs, d_R, d_R + 5 * plane, 10 * plane, d_flow, width, height, d_M);
+}
+
+extern "C" int nsof_stage_blur_solve(nsof_ctx* ctx, int n_pairs, const float* d_M, int width, int height,
+                                     int winsize, float* d_flow)
+{
+    if (!ctx || !d_M || !d_flow || n_pairs < 1 || width < 1 || height < 1 || winsize < 2) return NSOF_EINVAL;
+    return nsof_launch_blur_solve(ctx, n_pairs, d_M, width, height, winsize, d_flow);
+}
+
+extern "C" int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* d_src, int sw, int sh, float* d_dst,
+                                        int dw, int dh, double pyr_scale)
+{
+    if (!ctx || !d_src || !d_dst || n_pairs < 1 || sw < 1 || sh < 1 || dw < 1 || dh < 1) return NSOF_EINVAL;
+    return nsof_launch_flow_upsample(ctx, n_pairs, d_src, sw, sh, d_dst, dw, dh, (float)(1. / pyr_scale));
+}
+
+// ---- the Farneback driver --------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
+                                           ptrdiff_t row_stride, ptrdiff_t pair_stride, int width, int height,
+                                           float* d_flow, double pyr_scale, int levels, int winsize, int iterations,
+                                           int poly_n, double poly_sigma, int flags)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (!d_prev || !d_next || !d_flow || n_pairs < 1) return nsof_set_error(ctx, NSOF_EINVAL, "null buffer or n_pairs<1");
+    int rc = check_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
+    if (rc) return rc;
+    if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+
+    nsof_poly_taps ptaps;
+    if ((rc = nsof_host_poly_taps(poly_n, poly_sigma, &ptaps))) return nsof_set_error(ctx, rc, "poly taps");
+    const int L = nsof_farneback_effective_levels(width, height, pyr_scale, levels);
+
+    // workspace: I [B][2][n0], R [B][2][5][n0], M [B][5][n0], coarse flow ping/pong [B][n1][2]
+    const size_t n0 = (size_t)width * height, B = (size_t)n_pairs;
+    size_t n1 = 0;
+    if (L >= 1) {
+        int w1, h1;
+        nsof_farneback_level_size(width, height, pyr_scale, 1, &w1, &h1, nullptr, nullptr);
+        n1 = (size_t)w1 * h1;
+    }
+    const size_t szI = align_up(B * 2 * n0 * 4, 256), szR = align_up(B * 10 * n0 * 4, 256);
+    const size_t szM = align_up(B * 5 * n0 * 4, 256), szF = align_up(B * n1 * 8, 256);
+    if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szM + 2 * szF))) return rc;
+    char* base = (char*)ctx->ws;
+    float* dI = (float*)base;
+    float* dR = (float*)(base + szI);
+    float* dM = (float*)(base + szI + szR);
+    float* dF[2] = {(float*)(base + szI + szR + szM), (float*)(base + szI + szR + szM + szF)};
+
+    const float* prev_flow = nullptr;
+    int pw = 0, ph = 0, pp = 0;
+    for (int k = L; k >= 0; k--) {
+        int wk, hk, ks;
+        double sg;
+        nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, &ks, &sg);
+        nsof_blur_taps btaps;
+        if ((rc = nsof_host_blur_taps(ks, sg, &btaps)))
+            return nsof_set_error(ctx, rc, "pyramid blur kernel size %d unsupported (max %d)", ks,
+                                  NSOF_MAX_BLUR_TAPS - 1);
+        const size_t nk = (size_t)wk * hk;
+        float* flow = (k == 0) ? d_flow : dF[pp];
+        if (!prev_flow) {
+            NSOF_HIP(ctx, hipMemsetAsync(flow, 0, B * nk * 8, ctx->stream));
+        } else {
+            if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, prev_flow, pw, ph, flow, wk, hk,
+                                                (float)(1. / pyr_scale))))
+                return rc;
+        }
+        // image-major batches: dI [2][B][hk][wk] (all prev frames, then all next frames),
+        // dR [2][B][5][hk][wk]; one prep launch per frame set, one polyexp launch for all 2B images.
+        for (int i = 0; i < 2; i++)
+            if ((rc = nsof_launch_prep(ctx, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width, height,
+                                       wk, hk, btaps, dI + (size_t)i * B * nk)))
+                return rc;
+        if ((rc = nsof_launch_polyexp(ctx, 2 * n_pairs, dI, wk, hk, ptaps, dR))) return rc;
+        const float* R0 = dR;
+        const float* R1 = dR + B * 5 * nk;
+        if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
+        for (int it = 0; it < iterations; it++) {
+            if ((rc = nsof_launch_blur_solve(ctx, n_pairs, dM, wk, hk, winsize, flow))) return rc;
+            if (it < iterations - 1)
+                if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
+        }
+        prev_flow = flow;
+        pw = wk;
+        ph = hk;
+        pp ^= 1;
+    }
+    return NSOF_OK;
+}
+
+extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t prev_stride, const uint8_t* next,
+                                 ptrdiff_t next_stride, int width, int height, float* flow, ptrdiff_t flow_stride,
+                                 double pyr_scale, int levels, int winsize, int iterations, int poly_n,
+                                 double poly_sigma, int flags)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (!prev || !next || !flow) return nsof_set_error(ctx, NSOF_EINVAL, "null image pointer");
+    int rc = check_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
+    if (rc) return rc;
+    if (flow_stride < (ptrdiff_t)(width * 8)) return nsof_set_error(ctx, NSOF_EINVAL, "flow_stride < width*8");
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pitch = align_up((size_t)width, 64), n0 = (size_t)width * height;
+    const size_t szU = align_up(pitch * height, 256), szF = align_up(n0 * 8, 256);
+    if ((rc = nsof_ws_reserve(ctx, &ctx->stage, &ctx->stage_bytes, 2 * szU + szF))) return rc;
+    uint8_t* dP = (uint8_t*)ctx->stage;
+    uint8_t* dN = dP + szU;
+    float* dFl = (float*)(dN + szU);
+    NSOF_HIP(ctx, hipMemcpy2DAsync(dP, pitch, prev, prev_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    NSOF_HIP(ctx, hipMemcpy2DAsync(dN, pitch, next, next_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    rc = nsof_farneback_u8_batch_dev(ctx, 1, dP, dN, (ptrdiff_t)pitch, (ptrdiff_t)szU, width, height, dFl, pyr_scale,
+                                     levels, winsize, iterations, poly_n, poly_sigma, flags);
+    if (rc) return rc;
+    NSOF_HIP(ctx, hipMemcpy2DAsync(flow, flow_stride, dFl, (size_t)width * 8, (size_t)width * 8, height,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NSOF_OK;
+}

@@ -1,0 +1,81 @@
+// Internal declarations shared by the HIP translation units of libnsof.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+#include "nsof.h"
+
+#define NSOF_MAX_POLY_N 10    // templated fast kernels exist for radius 1..10 (reference uses 1, 5, 10)
+#define NSOF_MAX_BLUR_TAPS 64 // pyramid Gaussian kernel size limit (reference needs <= 19)
+
+struct nsof_prof_slot {
+    std::vector<hipEvent_t> start, stop;  // event pool, reused
+    size_t used = 0;
+    double acc_ms = 0;       // already-collected time
+    long long acc_launches = 0;
+};
+
+struct nsof_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    unsigned prof_mask = 0;
+    nsof_prof_slot prof[NSOF_K_COUNT];
+    char err[512] = {0};
+    // reusable device workspace of the Farneback driver
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // staging for the host-pointer entry point
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
+int nsof_ws_reserve(nsof_ctx* ctx, void** buf, size_t* cur, size_t need);
+
+#define NSOF_HIP(ctx, call)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return nsof_set_error((ctx), NSOF_EDEVICE, "%s failed: %s (%s:%d)", #call,           \
+                                  hipGetErrorString(e_), __FILE__, __LINE__);                    \
+    } while (0)
+
+// Event bracketing of one launch when profiling of kernel `id` is enabled.
+struct nsof_prof_scope {
+    nsof_ctx* ctx;
+    int id;
+    bool on;
+    nsof_prof_scope(nsof_ctx* c, int k);
+    ~nsof_prof_scope();
+};
+
+// ---- Farneback launchers (farneback_kernels.hip) ------------------------------------------
+struct nsof_blur_taps {
+    int ksize;
+    float k[NSOF_MAX_BLUR_TAPS];
+};
+struct nsof_poly_taps {
+    int n;
+    float g[NSOF_MAX_POLY_N + 1], xg[NSOF_MAX_POLY_N + 1], xxg[NSOF_MAX_POLY_N + 1];
+    double dg[NSOF_MAX_POLY_N + 1], dxxg[NSOF_MAX_POLY_N + 1];
+    double ig11, ig03, ig33, ig55;
+};
+
+int nsof_host_blur_taps(int ksize, double sigma, nsof_blur_taps* out);
+int nsof_host_poly_taps(int n, double sigma, nsof_poly_taps* out);
+
+// All launchers are asynchronous on ctx->stream and return an nsof_status.
+int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
+                     int H, int wk, int hk, const nsof_blur_taps& taps, float* out);
+int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps,
+                        float* R);
+// R0/R1: planar [5][h][w] expansion of prev/next of pair 0; pair z is at +z*pair_stride floats.
+int nsof_launch_update_matrices(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                                const float* flow, int W, int H, float* M);
+int nsof_launch_blur_solve(nsof_ctx* ctx, int n_pairs, const float* M, int W, int H, int winsize, float* flow);
+int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw,
+                              int dh, float mul);

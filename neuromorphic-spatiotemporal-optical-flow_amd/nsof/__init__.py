@@ -1,0 +1,23 @@
+"""nsof -- MI355X-native neuromorphic optical-flow core (host-side Python mirror).
+
+Mirrors the two interfaces the reference's scripts call on the hot path:
+
+* ``calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations,
+  poly_n, poly_sigma, flags)`` -- same positional order and keyword names as
+  ``cv2.calcOpticalFlowFarneback`` at /root/reference/optical_flow_seg.py:203
+  (``farneback_params`` dict at :73-81); ``install()`` assigns it onto ``cv2`` so the
+  reference's seg/ob/prediction scripts run unmodified where cv2 exists.
+* ``simulate(...)``, ``update_state(w, V)``, ``resistance_exp(w)`` -- the accumulator of
+  /root/reference/eventsim/event_mem_sim.py:40-63,164-286.
+
+All arithmetic runs in libnsof.so (HIP, gfx950).  No fallbacks.
+"""
+from .errors import NsofError, error  # noqa: F401
+from .context import Context, default_context  # noqa: F401
+from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_levels, farneback_batch,  # noqa: F401
+                        install, level_size, uninstall)
+from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, load_events, resistance_exp,  # noqa: F401
+                          simulate, slice_indices, update_state)
+
+__all__ = ["calcOpticalFlowFarneback", "install", "uninstall", "FarnebackParams", "farneback_batch", "Context",
+           "default_context", "simulate", "update_state", "resistance_exp", "Accumulator", "NsofError", "error"]

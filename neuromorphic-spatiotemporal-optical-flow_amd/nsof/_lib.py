@@ -1,0 +1,90 @@
+"""ctypes binding of libnsof.so (the C ABI declared in include/nsof.h).
+
+The shared library is the product: if it is missing or cannot be loaded this module
+raises -- there is no Python / CPU fallback path.
+"""
+import ctypes as C
+import importlib.util
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsof.so")
+
+NSOF_OK, NSOF_EINVAL, NSOF_ESHAPE, NSOF_EDEVICE, NSOF_ENOMEM, NSOF_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_COUNT = range(7)
+
+_vp, _i, _d, _f, _sz, _pd, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t, C.c_ssize_t, C.c_int64
+
+# name -> (restype, argtypes); every symbol include/nsof.h declares
+SIGNATURES = {
+    "nsof_create": (_i, [_i, C.POINTER(_vp)]),
+    "nsof_destroy": (None, [_vp]),
+    "nsof_last_error": (C.c_char_p, [_vp]),
+    "nsof_abi_version": (_i, []),
+    "nsof_set_stream": (_i, [_vp, _vp]),
+    "nsof_synchronize": (_i, [_vp]),
+    "nsof_farneback_u8": (_i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp, _pd, _d, _i, _i, _i, _i, _d, _i]),
+    "nsof_farneback_u8_batch_dev": (_i, [_vp, _i, _vp, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
+    "nsof_farneback_effective_levels": (_i, [_i, _i, _d, _i]),
+    "nsof_farneback_level_size": (_i, [_i, _i, _d, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_d)]),
+    "nsof_stage_pyr_level": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _d, _i, _vp]),
+    "nsof_stage_polyexp": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _vp]),
+    "nsof_stage_update_matrices": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    "nsof_stage_blur_solve": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "nsof_stage_flow_upsample": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _d]),
+    "nsof_prof_enable": (_i, [_vp, C.c_uint]),
+    "nsof_prof_collect": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),
+    "nsof_kernel_name": (C.c_char_p, [_i]),
+    "nsof_accum_create": (_i, [_vp, _i, _i, _i, _i, _f, _f, C.POINTER(_vp)]),
+    "nsof_accum_destroy": (None, [_vp]),
+    "nsof_accum_set_dense": (_i, [_vp, _i]),
+    "nsof_accum_reset": (_i, [_vp]),
+    "nsof_accum_step_events": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
+    "nsof_accum_update_state_dev": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "nsof_accum_resistance_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "nsof_accum_read_w": (_i, [_vp, _i, _vp]),
+    "nsof_accum_read_resistance": (_i, [_vp, _i, _vp]),
+    "nsof_accum_snapshot_count": (_i64, [_vp]),
+    "nsof_accum_read_snapshots": (_i, [_vp, _i, _vp, _i64]),
+    "nsof_accum_slice_bounds": (_i64, [_vp, _i64, _i64, _vp, _i64]),
+}
+
+_lib = None
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, same as the system ROCm one libnsof.so is linked against).  If libnsof.so pulled in the
+    system runtime first and torch were imported later, the process would hold two HIP/HSA runtimes and the
+    second one finds no GPU.  Loading torch's copy first makes the dynamic loader satisfy libnsof.so's
+    DT_NEEDED from it (soname match), whichever order the caller imports things in.
+    NSOF_HIP_RUNTIME=system skips this (for processes that never import torch)."""
+    if os.environ.get("NSOF_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load():
+    """Load libnsof.so (once).  Raises OSError with a build hint if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(
+                f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(_HERE)}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`); nsof has no CPU fallback")
+        _preload_torch_hip_runtime()
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

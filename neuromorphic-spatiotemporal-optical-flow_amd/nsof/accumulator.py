@@ -1,0 +1,220 @@
+"""Synaptic accumulator: host-side mirror of /root/reference/eventsim/event_mem_sim.py.
+
+Same names and argument meaning as the reference (``PARAMS``, ``DT``, ``update_state(w, V)``,
+``resistance_exp(w)``, ``slice_indices(t, slice_us)``, ``load_events(h5_path)``, ``simulate(...)``);
+the arithmetic runs in libnsof.so on the GPU.
+"""
+import ctypes as C
+import gzip
+import json
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from .context import default_context, dev_ptr
+from .errors import NsofValueError
+
+# event_mem_sim.py:20-34 (informational mirror; the device constants are compiled into libnsof.so)
+PARAMS = dict(alphaoff=1, alphaon=1, voff=-0.2, von=0.1, koff=51.03, kon=-2.91, son=0.2, soff=0.8,
+              bon=-5.12, boff=3.10, Ron=163_305, Roff=2_104_377, won=1, woff=0, wini=0.5)
+DT = 5e-4
+THETA_EVENTS = 1
+REFRACTORY_US = 800
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def update_state(w, V, *, ctx=None):  # noqa: N803
+    """``update_state(w, V)`` of event_mem_sim.py:40-57 for float32 arrays (numpy in -> numpy out)."""
+    ctx = ctx or default_context()
+    w = np.ascontiguousarray(w, np.float32)
+    V = np.ascontiguousarray(V, np.float32)  # noqa: N806
+    if w.shape != V.shape:
+        raise NsofValueError(f"w {w.shape} and V {V.shape} shapes differ", _lib.NSOF_ESHAPE)
+    torch = _torch()
+    dev = torch.device("cuda", ctx.device)
+    dw, dv = torch.from_numpy(w).to(dev), torch.from_numpy(V).to(dev)
+    out = torch.empty_like(dw)
+    torch.cuda.synchronize(dev)
+    ctx.check(ctx._lib.nsof_accum_update_state_dev(ctx.ptr, dev_ptr(dw), dev_ptr(dv), dev_ptr(out), w.size),
+              "update_state")
+    ctx.synchronize()
+    return out.cpu().numpy()
+
+
+def resistance_exp(w, *, ctx=None):
+    """``resistance_exp(w)`` of event_mem_sim.py:60-63, returned as float32 (as the reference stores it, :292)."""
+    ctx = ctx or default_context()
+    w = np.ascontiguousarray(w, np.float32)
+    torch = _torch()
+    dev = torch.device("cuda", ctx.device)
+    dw = torch.from_numpy(w).to(dev)
+    out = torch.empty_like(dw)
+    torch.cuda.synchronize(dev)
+    ctx.check(ctx._lib.nsof_accum_resistance_dev(ctx.ptr, dev_ptr(dw), dev_ptr(out), w.size), "resistance_exp")
+    ctx.synchronize()
+    return out.cpu().numpy()
+
+
+def slice_index_array(t, slice_us):
+    """searchsorted(t, arange(t[0], t[-1]+slice_us, slice_us)) of event_mem_sim.py:78-83 as one int64 array."""
+    t = np.ascontiguousarray(t, np.int64)
+    lib = _lib.load()
+    n = lib.nsof_accum_slice_bounds(t.ctypes.data, t.size, int(slice_us), None, 0)
+    idx = np.empty(n, np.int64)
+    lib.nsof_accum_slice_bounds(t.ctypes.data, t.size, int(slice_us), idx.ctypes.data, n)
+    return idx
+
+
+def slice_indices(t, slice_us):
+    """Generator of ``slice(start, stop)`` objects, as the reference's ``slice_indices``."""
+    idx = slice_index_array(t, slice_us)
+    for i in range(len(idx) - 1):
+        yield slice(int(idx[i]), int(idx[i + 1]))
+
+
+def load_events(h5_path):
+    """``load_events`` of event_mem_sim.py:69-75 (needs h5py; sensor size inferred from the data)."""
+    import h5py
+    with h5py.File(h5_path, "r") as f:
+        evs = f["/CD/events"]
+        x, y, p, t = evs["x"][:], evs["y"][:], evs["p"][:].astype(int), evs["t"][:]
+    H, W = int(y.max()) + 1, int(x.max()) + 1  # noqa: N806
+    return x, y, p, t, H, W
+
+
+class Accumulator:
+    """Device-resident array state (w, refractory maps) that can be advanced chunk by chunk."""
+
+    def __init__(self, height, width, version=1, polarity="split", active_v=-8.0, silent_v=0.0, *, ctx=None,
+                 dense=False):
+        if version not in (1, 2):
+            raise NsofValueError("version must be 1 or 2")
+        if polarity not in ("split", "magnitude"):
+            raise NsofValueError("polarity must be 'split' or 'magnitude'")
+        self.ctx = ctx or default_context()
+        self.H, self.W, self.version = int(height), int(width), version
+        self.split = version == 2 and polarity == "split"
+        p = C.c_void_p()
+        self.ctx.check(self.ctx._lib.nsof_accum_create(self.ctx.ptr, self.H, self.W, version, int(self.split),
+                                                       float(active_v), float(silent_v), C.byref(p)), "accum_create")
+        self._p = p
+        if dense:
+            self.ctx.check(self.ctx._lib.nsof_accum_set_dense(self._p, 1), "accum_set_dense")
+
+    def reset(self):
+        self.ctx.check(self.ctx._lib.nsof_accum_reset(self._p), "accum_reset")
+
+    def step(self, x, y, p, t, bounds, snap_every=0):
+        """Advance over slices ``[bounds[i], bounds[i+1])`` of the host event arrays."""
+        x = np.ascontiguousarray(x, np.int16)
+        y = np.ascontiguousarray(y, np.int16)
+        p = np.ascontiguousarray(p, np.int8)
+        t = np.ascontiguousarray(t, np.int64)
+        bounds = np.ascontiguousarray(bounds, np.int64)
+        if bounds.size < 2:
+            return
+        if bounds[-1] > x.size or not (x.size == y.size == p.size == t.size):
+            raise NsofValueError("event arrays shorter than the slice bounds")
+        self.ctx.check(self.ctx._lib.nsof_accum_step_events(self._p, x.ctypes.data, y.ctypes.data, p.ctypes.data,
+                                                            t.ctypes.data, bounds.ctypes.data, bounds.size - 1,
+                                                            int(snap_every)), "accum_step_events")
+
+    def w(self, which=0):
+        out = np.empty((self.H, self.W), np.float32)
+        self.ctx.check(self.ctx._lib.nsof_accum_read_w(self._p, which, out.ctypes.data), "accum_read_w")
+        return out
+
+    def resistance(self, which=0):
+        out = np.empty((self.H, self.W), np.float32)
+        self.ctx.check(self.ctx._lib.nsof_accum_read_resistance(self._p, which, out.ctypes.data), "accum_read_R")
+        return out
+
+    def snapshots(self):
+        """-> list (one per array) of float32 [count][H][W]; clears the device ring."""
+        n = self.ctx._lib.nsof_accum_snapshot_count(self._p)
+        outs = []
+        for which in range(2 if self.split else 1):
+            out = np.empty((n, self.H, self.W), np.float32)
+            self.ctx.check(self.ctx._lib.nsof_accum_read_snapshots(self._p, which, out.ctypes.data, n),
+                           "accum_read_snapshots")
+            outs.append(out)
+        return outs
+
+    def close(self):
+        if getattr(self, "_p", None) is not None:
+            self.ctx._lib.nsof_accum_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def simulate(events, version=1, slice_us=1_000, active_v=-8.0, silent_v=0.0, save_video=False, polarity="split",
+             *, sensor_size=None, out_prefix=None, ctx=None, dense=False):
+    """``simulate`` of event_mem_sim.py:164-286.
+
+    ``events``: an HDF5 path with a ``/CD/events`` group (as the reference) or a tuple ``(x, y, p, t)`` of arrays.
+    Returns ``dict(w_final, resistances[, w_final_b, resistances_b])`` with the reference's snapshot cadence
+    (every ``max(1, nslices // 100)`` slices).  With ``out_prefix`` (or an HDF5 path) the same
+    ``.V{version}.npz`` / ``.V2_b.npz`` / ``.json.gz`` files as the reference (:289-322) are written.
+    ``save_video`` is accepted for signature compatibility; MP4 previews are not produced.
+    """
+    if version not in (1, 2):
+        raise NsofValueError("version must be 1 or 2")
+    if polarity not in ("split", "magnitude"):
+        raise NsofValueError("polarity must be 'split' or 'magnitude'")
+    h5_path = None
+    if isinstance(events, (str, Path)):
+        h5_path = Path(events)
+        x, y, p, t, H, W = load_events(h5_path)  # noqa: N806
+    else:
+        x, y, p, t = events
+        x, y, t = np.asarray(x), np.asarray(y), np.asarray(t)
+        if x.size == 0:
+            raise NsofValueError("empty event stream")
+        if sensor_size is None:
+            H, W = int(y.max()) + 1, int(x.max()) + 1  # noqa: N806  (event_mem_sim.py:74)
+        else:
+            H, W = sensor_size  # noqa: N806
+    idx = slice_index_array(t, slice_us)
+    nslices = max(len(idx) - 1, 0)
+    every = max(1, nslices // 100)
+    acc = Accumulator(H, W, version, polarity, active_v, silent_v, ctx=ctx, dense=dense)
+    try:
+        acc.step(x, y, p, t, idx, snap_every=every)
+        snaps = acc.snapshots()
+        out = dict(w_final=acc.w(0), resistances=snaps[0])
+        if acc.split:
+            out.update(w_final_b=acc.w(1), resistances_b=snaps[1])
+    finally:
+        acc.close()
+    prefix = Path(out_prefix) if out_prefix is not None else h5_path
+    if prefix is not None:
+        _save_outputs(prefix, out, version, slice_us, polarity, h5_path)
+    return out
+
+
+def _save_outputs(prefix, out, version, slice_us, polarity, h5_path):
+    """File set of event_mem_sim.py:289-322 (npz keys ``w_final`` / ``resistances``; json.gz metadata)."""
+    np.savez_compressed(prefix.with_suffix(f".V{version}.npz"), w_final=out["w_final"],
+                        resistances=out["resistances"].astype(np.float32))
+    if version == 2:
+        if "w_final_b" in out:
+            np.savez_compressed(prefix.with_suffix(".V2_b.npz"), w_final=out["w_final_b"],
+                                resistances=out["resistances_b"].astype(np.float32))
+        else:
+            np.savez_compressed(prefix.with_suffix(".V2_b.npz"), w_final=np.array([]), resistances=np.array([]))
+    meta = dict(version=version, slice_us=slice_us, fps=1_000_000 / slice_us, params=PARAMS, dt=DT,
+                scheme="boxcar" if version == 1 else "dc_bias_overlay", polarity=polarity if version == 2 else None,
+                theta_events=THETA_EVENTS if version == 1 else None,
+                refractory_us=REFRACTORY_US if version == 2 else None, event_file=str(h5_path or prefix))
+    with gzip.open(prefix.with_suffix(f".V{version}.json.gz"), "wt") as fp:
+        json.dump(meta, fp, indent=2)

@@ -1,0 +1,127 @@
+"""Dense Farneback flow: drop-in for ``cv2.calcOpticalFlowFarneback``.
+
+Reference call sites: /root/reference/optical_flow_seg.py:158,203,494 (and the _ob/_prediction/
+_yolo twins); always ``(prev_region, next_region, None, **farneback_params)`` with the keys
+``pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags`` (:73-81); inputs may be
+strided ROI views ``gray[y0:y1, x0:x1]`` (:186-187).
+"""
+import ctypes as C
+from dataclasses import asdict, dataclass
+
+import numpy as np
+
+from . import _lib
+from .context import default_context, dev_ptr
+from .errors import NsofValueError
+
+
+@dataclass(frozen=True)
+class FarnebackParams:
+    """Keyword set of the reference's ``farneback_params`` dict (optical_flow_seg.py:73-81)."""
+    pyr_scale: float = 0.5
+    levels: int = 3
+    winsize: int = 15
+    iterations: int = 3
+    poly_n: int = 5
+    poly_sigma: float = 1.2
+    flags: int = 0
+
+    def as_kwargs(self):
+        return asdict(self)
+
+
+# parameter sets the reference ships (data/*/Parameters.txt)
+PARAMS_A = FarnebackParams(0.5, 3, 15, 3, 5, 1.2, 0)    # grasp, uavnew2
+PARAMS_B = FarnebackParams(0.6, 3, 3, 3, 10, 1.05, 0)   # autodriving, uav
+PARAMS_C = FarnebackParams(0.6, 3, 4, 2, 1, 1.05, 0)    # tabletennis
+
+
+def _as_gray_u8(a, name):
+    if not isinstance(a, np.ndarray):
+        raise NsofValueError(f"{name} is not a numpy array (got {type(a).__name__})")
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    if a.ndim != 2:
+        raise NsofValueError(f"{name} must be single-channel (shape {a.shape}); cv2 asserts channels() == 1")
+    if a.dtype != np.uint8:
+        raise NsofValueError(f"{name} must be uint8 (got {a.dtype}); the reference only passes 8-bit gray frames")
+    if a.size and a.strides[1] != 1:  # pixel stride must be 1; row stride is free (ROI views)
+        a = np.ascontiguousarray(a)
+    return a
+
+
+def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags,  # noqa: A002,N802
+                             *, ctx=None):
+    """Same signature and result as ``cv2.calcOpticalFlowFarneback``: float32 (H, W, 2), (u, v) interleaved,
+    such that ``next(x+u, y+v) ~ prev(x, y)``.  ``flow=None`` allocates; a matching float32 array is reused."""
+    prev = _as_gray_u8(prev, "prev")
+    next = _as_gray_u8(next, "next")  # noqa: A001
+    if prev.shape != next.shape:
+        raise NsofValueError(f"prev {prev.shape} and next {next.shape} sizes differ", _lib.NSOF_ESHAPE)
+    h, w = prev.shape
+    if h == 0 or w == 0:
+        raise NsofValueError("empty input image", _lib.NSOF_ESHAPE)
+    if (isinstance(flow, np.ndarray) and flow.dtype == np.float32 and flow.shape == (h, w, 2)
+            and flow.strides[2] == 4 and flow.strides[1] == 8 and flow.flags.writeable):
+        out = flow
+    else:
+        out = np.empty((h, w, 2), np.float32)
+    ctx = ctx or default_context()
+    rc = ctx._lib.nsof_farneback_u8(ctx.ptr, prev.ctypes.data, prev.strides[0], next.ctypes.data, next.strides[0],
+                                    w, h, out.ctypes.data, out.strides[0], float(pyr_scale), int(levels),
+                                    int(winsize), int(iterations), int(poly_n), float(poly_sigma), int(flags))
+    ctx.check(rc, "calcOpticalFlowFarneback")
+    return out
+
+
+def farneback_batch(d_prev, d_next, d_flow, n_pairs, height, width, params, *, row_stride=None, pair_stride=None,
+                    ctx=None):
+    """Device-resident batch: ``d_prev/d_next`` uint8 [n][H][row_stride], ``d_flow`` float32 [n][H][W][2]
+    (torch tensors or raw device addresses).  Asynchronous on the context's stream."""
+    ctx = ctx or default_context()
+    row_stride = width if row_stride is None else row_stride
+    pair_stride = row_stride * height if pair_stride is None else pair_stride
+    p = params
+    rc = ctx._lib.nsof_farneback_u8_batch_dev(ctx.ptr, n_pairs, dev_ptr(d_prev), dev_ptr(d_next), row_stride,
+                                              pair_stride, width, height, dev_ptr(d_flow), p.pyr_scale, p.levels,
+                                              p.winsize, p.iterations, p.poly_n, p.poly_sigma, p.flags)
+    ctx.check(rc, "farneback_batch")
+
+
+def effective_levels(width, height, pyr_scale, levels):
+    return _lib.load().nsof_farneback_effective_levels(width, height, pyr_scale, levels)
+
+
+def level_size(width, height, pyr_scale, level):
+    """-> (level_width, level_height, blur_ksize, blur_sigma)"""
+    lw, lh, ks, sg = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    rc = _lib.load().nsof_farneback_level_size(width, height, pyr_scale, level, C.byref(lw), C.byref(lh),
+                                               C.byref(ks), C.byref(sg))
+    if rc:
+        raise NsofValueError(f"bad level geometry ({width}x{height}, pyr_scale={pyr_scale}, level={level})", rc)
+    return lw.value, lh.value, ks.value, sg.value
+
+
+_saved_cv2_fn = None
+
+
+def install(cv2_module=None):
+    """Assign ``calcOpticalFlowFarneback`` onto ``cv2`` (the reference looks the attribute up at call
+    time, so its scripts then run on the GPU unmodified).  Returns the patched module."""
+    global _saved_cv2_fn
+    if cv2_module is None:
+        import cv2 as cv2_module  # raises ImportError where cv2 is absent: nothing to patch
+    if _saved_cv2_fn is None:
+        _saved_cv2_fn = getattr(cv2_module, "calcOpticalFlowFarneback", None)
+    cv2_module.calcOpticalFlowFarneback = calcOpticalFlowFarneback
+    return cv2_module
+
+
+def uninstall(cv2_module=None):
+    global _saved_cv2_fn
+    if cv2_module is None:
+        import cv2 as cv2_module
+    if _saved_cv2_fn is not None:
+        cv2_module.calcOpticalFlowFarneback = _saved_cv2_fn
+        _saved_cv2_fn = None
+    return cv2_module

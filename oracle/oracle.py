@@ -75,7 +75,9 @@ def _chk(rc, what):
 
 def _u8(a):
     a = np.asarray(a)
-    assert a.dtype == np.uint8 and a.ndim == 2 and a.strides[1] == 1
+    assert a.dtype == np.uint8 and a.ndim == 2
+    if a.strides[1] != 1:
+        a = np.ascontiguousarray(a)
     return a
 
 

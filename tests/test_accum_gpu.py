@@ -1,0 +1,118 @@
+"""GPU parity: HIP accumulator (through the C ABI) vs the reference-generated golden vectors and the oracle.
+
+Tolerances: the state update uses float32 pow; the reference's NumPy (SVML pow), glibc powf (oracle) and the
+device (double-precision exp/log, rounded once) differ by <= 1 float ulp per step, so w is compared at
+5e-7 absolute (about 8 ulp at w ~ 0.5..1) after 50-400 slices and resistances at 2e-6 relative."""
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+W_ATOL = 5e-7
+R_RTOL = 2e-6
+CASES = ["v1", "v2_split", "v2_magnitude", "v1_leak", "v2_split_bias", "v1_exact", "v2_split_pm1"]
+
+
+def test_update_state_golden(nsof_lib, ctx):
+    g = np.load(golden_path("accum_update_state.npz"))
+    out = nsof_lib.update_state(g["w_grid"], g["V_grid"], ctx=ctx)
+    assert out.dtype == np.float32 and out.shape == g["w_grid"].shape
+    assert np.abs(out - g["out_grid"]).max() <= 1.2e-7
+    out = nsof_lib.update_state(g["w_rand"], g["V_rand"], ctx=ctx)
+    assert np.abs(out - g["out_rand"]).max() <= 1.2e-7
+    # known answers recorded in SURVEY.md section 8c (w0 = 0.5)
+    V = np.array([-8, -6, -1, -0.21, -0.2, 0, 0.1, 0.11, 1, 3], np.float32)
+    want = np.array([0.7042345, 0.6518667, 0.5209471, 0.50026184, 0.5, 0.5, 0.5, 0.49975047, 0.47754133, 0.4276332],
+                    np.float32)
+    got = nsof_lib.update_state(np.full(V.shape, 0.5, np.float32), V, ctx=ctx)
+    assert np.abs(got - want).max() <= 6e-8
+
+
+def test_resistance_golden(nsof_lib, ctx):
+    g = np.load(golden_path("accum_update_state.npz"))
+    r = nsof_lib.resistance_exp(g["w_rand"], ctx=ctx)
+    assert (np.abs(r - g["res_rand"]) / g["res_rand"]).max() <= R_RTOL
+    r = nsof_lib.resistance_exp(np.array([0.5, 0.6518667, 0.50026184], np.float32), ctx=ctx)
+    assert np.allclose(r, [586221.1990, 397622.2887, 585828.9265], rtol=R_RTOL)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_simulate_vs_reference_golden(nsof_lib, ctx, oracle, name):
+    d = np.load(golden_path(f"accum_sim_{name}.npz"))
+    H, W = d["w_final"].shape
+    out = nsof_lib.simulate((d["x"], d["y"], d["p"], d["t"]), version=int(d["version"]),
+                            slice_us=int(d["slice_us"]), active_v=float(d["active_v"]),
+                            silent_v=float(d["silent_v"]), polarity=str(d["polarity"]), sensor_size=(H, W), ctx=ctx)
+    assert out["resistances"].shape[0] == int(d["n_snapshots"])
+    assert np.abs(out["w_final"] - d["w_final"]).max() <= W_ATOL
+    idx = d["snap_idx"]
+    rr = out["resistances"][idx]
+    assert (np.abs(rr - d["resistances"]) / d["resistances"]).max() <= R_RTOL
+    if "w_final_b" in d:
+        assert np.abs(out["w_final_b"] - d["w_final_b"]).max() <= W_ATOL
+        assert (np.abs(out["resistances_b"][idx] - d["resistances_b"]) / d["resistances_b"]).max() <= R_RTOL
+    else:
+        assert "w_final_b" not in out
+    # and against the C oracle on every snapshot
+    ref = oracle.accum_simulate(d["x"], d["y"], d["p"], d["t"], H, W, int(d["version"]), str(d["polarity"]),
+                                int(d["slice_us"]), float(d["active_v"]), float(d["silent_v"]))
+    assert np.abs(out["w_final"] - ref["w_final"]).max() <= W_ATOL
+    assert (np.abs(out["resistances"] - ref["resistances"]) / ref["resistances"]).max() <= R_RTOL
+
+
+@pytest.mark.parametrize("name", ["v1", "v2_split", "v2_magnitude"])
+def test_dense_path_equals_sparse_path(nsof_lib, ctx, name):
+    """With silent_v in the dead zone the event-pixel (sparse) path must equal the every-pixel path bit for bit."""
+    d = np.load(golden_path(f"accum_sim_{name}.npz"))
+    H, W = d["w_final"].shape
+    kw = dict(version=int(d["version"]), slice_us=int(d["slice_us"]), active_v=float(d["active_v"]),
+              silent_v=float(d["silent_v"]), polarity=str(d["polarity"]), sensor_size=(H, W), ctx=ctx)
+    ev = (d["x"], d["y"], d["p"], d["t"])
+    a = nsof_lib.simulate(ev, **kw)
+    b = nsof_lib.simulate(ev, dense=True, **kw)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_chunked_stepping_equals_one_shot(nsof_lib, ctx):
+    d = np.load(golden_path("accum_sim_v2_split.npz"))
+    H, W = d["w_final"].shape
+    from nsof.accumulator import Accumulator, slice_index_array
+    idx = slice_index_array(d["t"], 1000)
+    every = max(1, (len(idx) - 1) // 100)
+    acc = Accumulator(H, W, 2, "split", -6.0, 0.0, ctx=ctx)
+    for lo in range(0, len(idx) - 1, 37):
+        acc.step(d["x"], d["y"], d["p"], d["t"], idx[lo:lo + 38], snap_every=every)
+    wa, wb = acc.w(0), acc.w(1)
+    snaps = acc.snapshots()
+    acc.close()
+    one = nsof_lib.simulate((d["x"], d["y"], d["p"], d["t"]), version=2, slice_us=1000, active_v=-6.0, silent_v=0.0,
+                            polarity="split", sensor_size=(H, W), ctx=ctx)
+    assert np.array_equal(wa, one["w_final"]) and np.array_equal(wb, one["w_final_b"])
+    assert np.array_equal(snaps[0], one["resistances"]) and np.array_equal(snaps[1], one["resistances_b"])
+
+
+def test_large_sensor_many_slices_vs_oracle(nsof_lib, ctx, oracle):
+    """1280x720 synthetic stream, 300 slices, scheme 1 and 2."""
+    from nsof import synth
+    x, y, p, t = synth.make_events(2024, 1280, 720, 60_000, 300_000)
+    for version, pol in [(1, "split"), (2, "split"), (2, "magnitude")]:
+        out = nsof_lib.simulate((x, y, p, t), version=version, slice_us=1000, active_v=-6.0, silent_v=0.0,
+                                polarity=pol, sensor_size=(720, 1280), ctx=ctx)
+        ref = oracle.accum_simulate(x, y, p, t, 720, 1280, version, pol, 1000, -6.0, 0.0)
+        assert np.abs(out["w_final"] - ref["w_final"]).max() <= W_ATOL
+        assert out["resistances"].shape == ref["resistances"].shape
+        assert (np.abs(out["resistances"][::17] - ref["resistances"][::17]) / ref["resistances"][::17]).max() <= R_RTOL
+        if "w_final_b" in ref:
+            assert np.abs(out["w_final_b"] - ref["w_final_b"]).max() <= W_ATOL
+
+
+def test_event_outside_sensor_is_rejected(nsof_lib, ctx):
+    x = np.array([5, 700], np.int16)
+    y = np.array([5, 5], np.int16)
+    p = np.array([1, 1], np.int8)
+    t = np.array([0, 10], np.int64)
+    with pytest.raises(nsof_lib.error):
+        nsof_lib.simulate((x, y, p, t), version=1, sensor_size=(64, 64), ctx=ctx)

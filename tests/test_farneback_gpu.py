@@ -1,0 +1,230 @@
+"""GPU parity: HIP Farneback (through the C ABI) vs the CPU oracle on identical inputs.
+
+Tolerances.  north_star asks for max-abs 1e-4 against cv2; the oracle restates cv2's arithmetic
+(parity unpinned: cv2 is not available, see oracle/farneback_ref.c).  The HIP path follows the same
+operation order, so the stage tests demand bit-exact results wherever the order is identical
+(pyramid level, polynomial expansion, matrix update, flow resample) and <= 2 float ulps where only the
+double-precision row-sum order differs (blur + solve).  Whole-pipeline tolerance: 1e-5 px.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+A = (0.5, 3, 15, 3, 5, 1.2, 0)
+B = (0.6, 3, 3, 3, 10, 1.05, 0)
+Cc = (0.6, 3, 4, 2, 1, 1.05, 0)
+PIPE_TOL = 1e-5
+
+
+def _dev(torch_dev, a):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(torch_dev)
+    torch.cuda.synchronize()  # libnsof launches on its own stream
+    return t
+
+
+def _planar(aos):  # (h,w,5) -> (5,h,w)
+    return np.ascontiguousarray(np.moveaxis(aos, -1, 0))
+
+
+@pytest.fixture(scope="module")
+def frames(nsof_lib):
+    from nsof import synth
+    return {(h, w): synth.make_pair(100 + h + w, h, w) for (h, w) in [(135, 240), (200, 303), (97, 131), (270, 480)]}
+
+
+@pytest.mark.parametrize("pyr_scale,level", [(0.5, 0), (0.5, 1), (0.5, 2), (0.5, 3), (0.6, 1), (0.6, 2), (0.6, 3),
+                                             (0.75, 2)])
+@pytest.mark.parametrize("shape", [(270, 480), (200, 303)])
+def test_pyr_level_bit_exact(ctx, oracle, torch_dev, frames, pyr_scale, level, shape):
+    import torch
+    img = frames[shape][0]
+    h, w = shape
+    want = oracle.pyr_level(img, pyr_scale, level)
+    hk, wk = want.shape
+    # two images in one launch, the second with a padded row stride
+    pitch = w + 13
+    buf = np.zeros((2, h, pitch), np.uint8)
+    buf[0, :, :w] = img
+    buf[1, :, :w] = frames[shape][1]
+    d = _dev(torch_dev, buf)
+    out = torch.empty((2, hk, wk), dtype=torch.float32, device=torch_dev)
+    ctx.check(ctx._lib.nsof_stage_pyr_level(ctx.ptr, 2, d.data_ptr(), pitch, h * pitch, w, h, pyr_scale, level,
+                                            out.data_ptr()))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0], want)
+    assert np.array_equal(got[1], oracle.pyr_level(frames[shape][1], pyr_scale, level))
+
+
+@pytest.mark.parametrize("n,sigma", [(1, 1.05), (2, 0.9), (3, 1.1), (5, 1.2), (7, 1.5), (10, 1.05), (4, 0.0)])
+@pytest.mark.parametrize("shape", [(135, 240), (97, 131), (33, 517)])
+def test_polyexp_bit_exact(ctx, oracle, torch_dev, n, sigma, shape):
+    import torch
+    rng = np.random.default_rng(n * 1000 + shape[0])
+    imgs = (rng.random((3,) + shape) * 255).astype(np.float32)
+    d = _dev(torch_dev, imgs)
+    out = torch.empty((3, 5) + shape, dtype=torch.float32, device=torch_dev)
+    ctx.check(ctx._lib.nsof_stage_polyexp(ctx.ptr, 3, d.data_ptr(), shape[1], shape[0], n, sigma, out.data_ptr()))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    for i in range(3):
+        want = _planar(oracle.polyexp(imgs[i], n, sigma))
+        assert np.array_equal(got[i], want), f"image {i}: max ulp {ulp_diff(got[i], want).max()}"
+
+
+def _level_state(oracle, prev, nxt, n, sigma, seed):
+    I0 = oracle.pyr_level(prev, 0.5, 0)
+    I1 = oracle.pyr_level(nxt, 0.5, 0)
+    R0, R1 = oracle.polyexp(I0, n, sigma), oracle.polyexp(I1, n, sigma)
+    rng = np.random.default_rng(seed)
+    flow = (rng.standard_normal(I0.shape + (2,)) * 3).astype(np.float32)
+    flow[:5, :7] += 40  # force out-of-image samples
+    return R0, R1, flow
+
+
+@pytest.mark.parametrize("shape", [(135, 240), (97, 131)])
+def test_update_matrices_bit_exact(ctx, oracle, torch_dev, frames, shape):
+    import torch
+    h, w = shape
+    prev, nxt = frames[shape]
+    R0, R1, flow = _level_state(oracle, prev, nxt, 5, 1.2, 5)
+    want = _planar(oracle.update_matrices(R0, R1, flow))
+    Rp = np.stack([np.stack([_planar(R0), _planar(R1)])] * 2)  # 2 pairs
+    flows = np.stack([flow, flow])
+    dR, dF = _dev(torch_dev, Rp), _dev(torch_dev, flows)
+    out = torch.empty((2, 5, h, w), dtype=torch.float32, device=torch_dev)
+    ctx.check(ctx._lib.nsof_stage_update_matrices(ctx.ptr, 2, dR.data_ptr(), dF.data_ptr(), w, h, out.data_ptr()))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+@pytest.mark.parametrize("winsize", [15, 3, 4, 2, 31])
+@pytest.mark.parametrize("shape", [(135, 240), (97, 531)])
+def test_blur_solve(ctx, oracle, torch_dev, winsize, shape):
+    import torch
+    from nsof import synth
+    h, w = shape
+    prev, nxt = synth.make_pair(9, h, w)
+    R0, R1, flow = _level_state(oracle, prev, nxt, 5, 1.2, 6)
+    M = oracle.update_matrices(R0, R1, flow)
+    want, _ = oracle.update_flow_blur(R0, R1, flow, M, winsize, False)
+    dM = _dev(torch_dev, _planar(M)[None])
+    out = torch.empty((1, h, w, 2), dtype=torch.float32, device=torch_dev)
+    ctx.check(ctx._lib.nsof_stage_blur_solve(ctx.ptr, 1, dM.data_ptr(), w, h, winsize, out.data_ptr()))
+    ctx.synchronize()
+    got = out.cpu().numpy()[0]
+    # column sums are order-identical; only the double row-sum order differs -> a few float ulps at most
+    d = np.abs(got - want)
+    assert d.max() <= 1e-6 * max(1.0, np.abs(want).max()), d.max()
+    assert (got != want).mean() < 0.01
+
+
+@pytest.mark.parametrize("pyr_scale,src,dst", [(0.5, (68, 120), (135, 240)), (0.6, (58, 79), (97, 131)),
+                                               (0.5, (135, 240), (270, 480))])
+def test_flow_upsample_bit_exact(ctx, oracle, torch_dev, pyr_scale, src, dst):
+    import torch
+    rng = np.random.default_rng(3)
+    f = (rng.standard_normal((2,) + src + (2,)) * 4).astype(np.float32)
+    d = _dev(torch_dev, f)
+    out = torch.empty((2,) + dst + (2,), dtype=torch.float32, device=torch_dev)
+    ctx.check(ctx._lib.nsof_stage_flow_upsample(ctx.ptr, 2, d.data_ptr(), src[1], src[0], out.data_ptr(), dst[1],
+                                                dst[0], pyr_scale))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    for i in range(2):
+        want = oracle.resize_linear(f[i], dst[1], dst[0]) * np.float32(1.0 / pyr_scale)
+        assert np.array_equal(got[i], want)
+
+
+@pytest.mark.parametrize("params", [A, B, Cc, (0.5, 1, 9, 1, 7, 1.5, 0), (0.8, 5, 7, 2, 3, 0.0, 0)],
+                         ids=["A", "B", "C", "D", "E"])
+@pytest.mark.parametrize("shape", [(135, 240), (200, 303), (97, 131)])
+def test_pipeline_vs_oracle(nsof_lib, ctx, oracle, frames, params, shape):
+    prev, nxt = frames[shape]
+    got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
+    want = oracle.farneback(prev, nxt, *params)
+    assert got.shape == want.shape and got.dtype == np.float32
+    err = np.abs(got - want).max()
+    assert err <= PIPE_TOL, f"max-abs {err}"
+
+
+def test_pipeline_1080p_vs_oracle(nsof_lib, ctx, oracle):
+    """BASELINE config 2 shape: one seeded synthetic 1920x1080 pair, params A and B."""
+    from nsof import synth
+    prev, nxt = synth.make_pair(1234, 1080, 1920)
+    for params in (A, B):
+        got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
+        want = oracle.farneback(prev, nxt, *params)
+        err = np.abs(got - want).max()
+        assert err <= PIPE_TOL, f"{params}: max-abs {err}"
+    # known motion is recovered (interior, params A)
+    got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=ctx)
+    tf = synth.true_flow(1080, 1920)
+    assert np.abs(got - tf)[100:-100, 100:-100].mean() < 0.05
+
+
+def test_roi_view_equals_standalone(nsof_lib, ctx, frames):
+    """A strided ROI view (optical_flow_seg.py:186-187) gives the same flow as a contiguous copy."""
+    prev, nxt = frames[(270, 480)]
+    pv, nv = prev[40:240, 60:363], nxt[40:240, 60:363]
+    assert not pv.flags.c_contiguous
+    a = nsof_lib.calcOpticalFlowFarneback(pv, nv, None, *A, ctx=ctx)
+    b = nsof_lib.calcOpticalFlowFarneback(pv.copy(), nv.copy(), None, *A, ctx=ctx)
+    assert np.array_equal(a, b)
+
+
+def test_flow_argument_reused_and_keywords(nsof_lib, ctx, frames):
+    prev, nxt = frames[(135, 240)]
+    kw = dict(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, flags=0)
+    buf = np.zeros((135, 240, 2), np.float32)
+    out = nsof_lib.calcOpticalFlowFarneback(prev, nxt, buf, **kw, ctx=ctx)
+    assert out is buf
+    ref = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, **kw, ctx=ctx)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(prev, frames[(135, 240)][0])  # inputs untouched
+
+
+def test_identical_frames_zero_interior(nsof_lib, ctx, frames):
+    prev, _ = frames[(270, 480)]
+    z = nsof_lib.calcOpticalFlowFarneback(prev, prev, None, *B, ctx=ctx)
+    assert np.abs(z[:150, :250]).max() == 0.0
+
+
+def test_batch_equals_single_calls(nsof_lib, ctx, torch_dev):
+    import torch
+    from nsof import synth
+    h, w, n = 120, 200, 5
+    pairs = [synth.make_pair(50 + i, h, w, shift=(1.0 + i, -0.5 * i)) for i in range(n)]
+    dp = _dev(torch_dev, np.stack([p for p, _ in pairs]))
+    dn = _dev(torch_dev, np.stack([q for _, q in pairs]))
+    df = torch.empty((n, h, w, 2), dtype=torch.float32, device=torch_dev)
+    P = nsof_lib.FarnebackParams(*A)
+    nsof_lib.farneback_batch(dp, dn, df, n, h, w, P, ctx=ctx)
+    ctx.synchronize()
+    got = df.cpu().numpy()
+    for i, (p, q) in enumerate(pairs):
+        one = nsof_lib.calcOpticalFlowFarneback(p, q, None, *A, ctx=ctx)
+        assert np.array_equal(got[i], one), i
+
+
+def test_error_behaviour(nsof_lib, ctx, frames):
+    prev, nxt = frames[(135, 240)]
+    with pytest.raises(nsof_lib.error):
+        nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, 1.0, 3, 15, 3, 5, 1.2, 0, ctx=ctx)  # pyr_scale < 1
+    with pytest.raises(nsof_lib.error):
+        nsof_lib.calcOpticalFlowFarneback(prev, nxt[:-1], None, *A, ctx=ctx)  # sizes differ
+    with pytest.raises(nsof_lib.error) as e:
+        nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, 0.5, 3, 15, 3, 5, 1.2, 4, ctx=ctx)
+    assert e.value.status == -5
+    with pytest.raises(nsof_lib.error):
+        nsof_lib.calcOpticalFlowFarneback(prev.astype(np.float32), nxt, None, *A, ctx=ctx)
+    # levels are truncated for small images (min_size 32), tiny images still work
+    small = nsof_lib.calcOpticalFlowFarneback(prev[:33, :40], nxt[:33, :40], None, *A, ctx=ctx)
+    assert small.shape == (33, 40, 2) and np.isfinite(small).all()
