@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1080p frame-pairs/s of the HIP Farneback path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one pass of the hot path over one batch of `--pairs` synthetic 1920x1080 frame pairs per
+GPU (inputs already resident in HBM, flow left in HBM), Farneback parameter set A of the reference
+(pyr_scale .5, levels 3, winsize 15, iterations 3, poly_n 5, poly_sigma 1.2, flags 0 --
+/root/reference/optical_flow_seg.py:73-81 and data/grasp/Parameters.txt).  Independent pairs are
+sharded over ranks with no data-path collective (weak scaling: fixed pairs per GPU); RCCL is used only
+for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+  roofline     -- dominant kernel by summed device time, timed live with HIP events on the launch
+                  stream inside the timed region; algorithmic bytes per DESIGN.md section "roofline"
+  roofline_polyexp -- the same for the polynomial-expansion kernel (the north-star kernel)
+  cpu_baseline -- the CPU oracle (oracle/farneback_ref.c, 1 thread) on a bounded sample of the same pairs
+  max_abs_epe_vs_oracle -- GPU flow vs oracle flow on that sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "neuromorphic-spatiotemporal-optical-flow_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def synth_pairs_gpu(torch, dev, n, h, w, seed0):
+    """n distinct textured u8 frame pairs generated on the device (same recipe as nsof.synth.make_pair:
+    blurred uniform noise, next = prev moved by a per-pair translation + 0.2 deg rotation)."""
+    import math
+    import torch.nn.functional as F  # noqa: N812
+    pad = 24
+    g = torch.Generator(device=dev)
+    prevs = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    nexts = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    r = 9
+    k = torch.exp(-torch.arange(-r, r + 1, device=dev, dtype=torch.float32) ** 2 / (2 * 3.0 * 3.0))
+    k = (k / k.sum())
+    ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
+                            torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
+    for i in range(n):
+        g.manual_seed(seed0 + i)
+        base = torch.rand((1, 1, h + 2 * pad, w + 2 * pad), generator=g, device=dev)
+        base = F.conv2d(F.pad(base, (r, r, 0, 0), mode="reflect"), k.view(1, 1, 1, -1))
+        base = F.conv2d(F.pad(base, (0, 0, r, r), mode="reflect"), k.view(1, 1, -1, 1))
+        base = (base - base.min()) / (base.max() - base.min()) * 255.0
+        u, v = 2.5 + 0.25 * (i % 5), -1.25 - 0.2 * (i % 3)
+        th = math.radians(0.2)
+        cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+        dx, dy = xs - cx - u, ys - cy - v
+        sx = math.cos(th) * dx + math.sin(th) * dy + cx + pad
+        sy = -math.sin(th) * dx + math.cos(th) * dy + cy + pad
+        hh, ww = h + 2 * pad, w + 2 * pad
+        grid = torch.stack([(sx + 0.5) / ww * 2 - 1, (sy + 0.5) / hh * 2 - 1], -1)[None]
+        nxt = F.grid_sample(base, grid, mode="bilinear", padding_mode="border", align_corners=False)
+        prevs[i] = base[0, 0, pad:pad + h, pad:pad + w].round().clamp(0, 255).to(torch.uint8)
+        nexts[i] = nxt[0, 0].round().clamp(0, 255).to(torch.uint8)
+    return prevs, nexts
+
+
+def level_sizes(nsof, w, h, p):
+    L = nsof.effective_levels(w, h, p.pyr_scale, p.levels)  # noqa: N806
+    return [nsof.level_size(w, h, p.pyr_scale, k)[:2] for k in range(L + 1)]
+
+
+def algorithmic_bytes_per_pair(nsof, w, h, p):
+    """Per-kernel compulsory HBM bytes for ONE frame pair (DESIGN.md 'roofline')."""
+    from nsof import _lib
+    sizes = level_sizes(nsof, w, h, p)
+    n0 = w * h
+    out = {k: 0 for k in range(_lib.K_COUNT)}
+    for k, (wk, hk) in enumerate(sizes):
+        nk = wk * hk
+        out[_lib.K_PREP] += 2 * (n0 + 4 * nk)                  # u8 frame in, f32 level image out, x2 frames
+        out[_lib.K_POLYEXP] += 2 * 24 * nk                     # 4 B read + 5x4 B written per pixel, x2 frames
+        out[_lib.K_UPDMAT] += p.iterations * 68 * nk           # R0 20 + R1 20 + flow 8 -> M 20
+        out[_lib.K_BLUR] += p.iterations * 28 * nk             # M 20 -> flow 8
+        if k + 1 < len(sizes):
+            nk1 = sizes[k + 1][0] * sizes[k + 1][1]
+            out[_lib.K_UPSAMPLE] += 8 * nk + 8 * nk1           # coarse flow in, fine flow out
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--params", choices=["A", "B", "C"], default="A")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import __graft_entry__ as ge
+    ge.build_native()
+    import nsof  # noqa: E402  (preloads torch's HIP runtime, then libnsof.so)
+    import torch
+    from nsof import _lib
+    from nsof.farneback import PARAMS_A, PARAMS_B, PARAMS_C
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    p = {"A": PARAMS_A, "B": PARAMS_B, "C": PARAMS_C}[args.params]
+    h, w, n = args.height, args.width, args.pairs
+    ctx = nsof.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    prevs, nexts = synth_pairs_gpu(torch, dev, n, h, w, 1234 + 1000 * rank)
+    flow = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+
+    def step():
+        nsof.farneback_batch(prevs, nexts, flow, n, h, w, p, ctx=ctx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ids = [_lib.K_PREP, _lib.K_POLYEXP, _lib.K_UPSAMPLE, _lib.K_UPDMAT, _lib.K_BLUR]
+    if not args.no_prof:
+        ctx.prof_enable(*kernel_ids)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = {}
+    if not args.no_prof:
+        for k in kernel_ids:
+            prof[k] = ctx.prof_collect(k)
+        ctx.prof_enable()
+
+    if rank == 0:
+        total_pairs = n * world * args.steps
+        alg = algorithmic_bytes_per_pair(nsof, w, h, p)
+
+        def roof(kid):
+            ms, launches = prof[kid]
+            if not launches:
+                return None
+            bytes_total = alg[kid] * n * args.steps           # this rank's launches moved this many algorithmic bytes
+            per_launch = bytes_total / launches
+            gbs = bytes_total / (ms * 1e-3) / 1e9
+            return {"kernel": _lib.load().nsof_kernel_name(kid).decode(), "bound": "hbm", "achieved": round(gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_us": round(ms * 1e3 / launches, 2), "launches": launches,
+                    "algorithmic_bytes_per_launch": int(per_launch)}
+
+        out = {
+            "metric": "1080p frame-pairs/sec (Farneback, HIP)" if (w, h) == (1920, 1080) else f"{w}x{h} frame-pairs/sec",
+            "value": round(total_pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{w}x{h} u8 frame pairs, Farneback params {args.params} "
+                                   f"(pyr_scale={p.pyr_scale}, levels={p.levels}, winsize={p.winsize}, "
+                                   f"iterations={p.iterations}, poly_n={p.poly_n}, poly_sigma={p.poly_sigma}, flags=0)",
+                       "pairs_per_gpu_per_step": n, "global_pairs_per_step": n * world,
+                       "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
+        }
+        if prof:
+            dom = max(kernel_ids, key=lambda k: prof[k][0])
+            out["roofline"] = roof(dom)
+            out["roofline_polyexp"] = roof(_lib.K_POLYEXP)
+            out["kernel_ms_per_step"] = {_lib.load().nsof_kernel_name(k).decode(): round(prof[k][0] / args.steps, 3)
+                                         for k in kernel_ids}
+            tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch
+            if os.path.exists(tj):
+                with open(tj) as f:
+                    tr = json.load(f)
+                for key in ("roofline", "roofline_polyexp"):
+                    ent = tr.get(cfg_key(args), {}).get(out[key]["kernel"]) if out.get(key) else None
+                    if ent is not None:
+                        out[key]["traffic"] = ent
+        if world == 1 and args.cpu_sample > 0:
+            out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cfg_key(args):
+    return f"{args.width}x{args.height}_{args.params}_{args.pairs}"
+
+
+def cpu_leg(nsof, p, prevs, nexts, flow, k):
+    """CPU oracle on the first k pairs of this run's batch: throughput (1 thread) and max-abs EPE GPU vs oracle."""
+    import numpy as np
+    from oracle import oracle as O  # noqa: N812  (the checker; only ever used here, in tests and in smoke())
+    O.build()
+    hp, hn, gf = prevs[:k].cpu().numpy(), nexts[:k].cpu().numpy(), flow[:k].cpu().numpy()
+    args = [getattr(p, a) for a in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    O.farneback(hp[0][:64, :64], hn[0][:64, :64], *args)  # load + warm the library
+    err = 0.0
+    t0 = time.perf_counter()
+    refs = [O.farneback(hp[i], hn[i], *args) for i in range(k)]
+    dt = time.perf_counter() - t0
+    for i in range(k):
+        err = max(err, float(np.abs(refs[i] - gf[i]).max()))
+    return {"cpu_baseline": {"value": round(k / dt, 4), "unit": "pairs/s", "cores": 1, "kind": "port",
+                             "sample": f"first {k} pairs of the timed batch, CPU oracle oracle/farneback_ref.c "
+                                       f"(gcc -O2, single thread; cv2 is not installed on this image)"},
+            "max_abs_epe_vs_oracle": err, "epe_tolerance": 1e-4}
+
+
+if __name__ == "__main__":
+    main()
