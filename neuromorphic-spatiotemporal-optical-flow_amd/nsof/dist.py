@@ -1,0 +1,88 @@
+"""Multi-GPU plumbing: independent frame pairs shard across ranks (one process per GPU).
+
+The path has no exchange step: every pair is independent, so the only
+communication is the optional scatter of uint8 frame batches from one rank and the gather of the float32
+flow back -- ``torch.distributed`` over RCCL ("nccl" backend on ROCm) on GPUs, gloo on CPU for tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world):
+    """Contiguous, balanced chunks: [(lo, hi)] * world (the first n_items % world ranks get one extra)."""
+    base, extra = divmod(n_items, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def shard_range(n_items, rank=None, world=None):
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return shard_bounds(n_items, world)[rank]
+
+
+def init_from_env(backend=None):
+    """Reads RANK / WORLD_SIZE / MASTER_* (torch.distributed.run); 127.0.0.1 rendezvous by default."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def scatter_pairs(prev_all, next_all, n_total, shape, device, src=0):
+    """Rank ``src`` holds uint8 tensors [n_total, H, W]; every rank returns its own shard
+    (prev, next) of shape [hi-lo, H, W] on ``device``.  Chunks are padded to equal length for dist.scatter."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bounds = shard_bounds(n_total, world)
+    cap = max(hi - lo for lo, hi in bounds)
+    h, w = shape
+    out = torch.empty((2, cap, h, w), dtype=torch.uint8, device=device)
+    chunks = None
+    if rank == src:
+        chunks = []
+        for lo, hi in bounds:
+            c = torch.zeros((2, cap, h, w), dtype=torch.uint8, device=device)
+            c[0, :hi - lo] = prev_all[lo:hi].to(device)
+            c[1, :hi - lo] = next_all[lo:hi].to(device)
+            chunks.append(c)
+    dist.scatter(out, chunks, src=src)
+    lo, hi = bounds[rank]
+    return out[0, :hi - lo].contiguous(), out[1, :hi - lo].contiguous()
+
+
+def gather_flows(flow_local, n_total, dst=0):
+    """Inverse of scatter_pairs: rank ``dst`` returns float32 [n_total, H, W, 2]; other ranks return None."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bounds = shard_bounds(n_total, world)
+    cap = max(hi - lo for lo, hi in bounds)
+    h, w = flow_local.shape[1:3]
+    buf = torch.zeros((cap, h, w, 2), dtype=torch.float32, device=flow_local.device)
+    buf[:flow_local.shape[0]] = flow_local
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, parts, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(bounds)], 0)
+
+
+def max_over_ranks(value, device="cpu"):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def run_sharded(prev_all, next_all, n_total, shape, device, compute, src=0):
+    """scatter -> ``compute(prev_shard, next_shard) -> flow_shard`` on every rank -> gather on ``src``."""
+    p, q = scatter_pairs(prev_all, next_all, n_total, shape, device, src)
+    flow = compute(p, q)
+    return gather_flows(flow, n_total, dst=src)
