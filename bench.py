@@ -84,6 +84,7 @@ def algorithmic_bytes_per_pair(nsof, w, h, p):
         out[_lib.K_POLYEXP] += 2 * 24 * nk                     # 4 B read + 5x4 B written per pixel, x2 frames
         out[_lib.K_UPDMAT] += p.iterations * 68 * nk           # R0 20 + R1 20 + flow 8 -> M 20
         out[_lib.K_BLUR] += p.iterations * 28 * nk             # M 20 -> flow 8
+        out[_lib.K_ITERATE] += p.iterations * 56 * nk          # fused: R0 20 + R1 20 + flow 8 -> flow 8
         if k + 1 < len(sizes):
             nk1 = sizes[k + 1][0] * sizes[k + 1][1]
             out[_lib.K_UPSAMPLE] += 8 * nk + 8 * nk1           # coarse flow in, fine flow out
@@ -143,7 +144,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ids = [_lib.K_PREP, _lib.K_POLYEXP, _lib.K_UPSAMPLE, _lib.K_UPDMAT, _lib.K_BLUR]
+    kernel_ids = [_lib.K_PREP, _lib.K_POLYEXP, _lib.K_UPSAMPLE, _lib.K_UPDMAT, _lib.K_BLUR, _lib.K_ITERATE]
     if not args.no_prof:
         ctx.prof_enable(*kernel_ids)
     barrier()

@@ -94,6 +94,10 @@ int nsof_stage_update_matrices(nsof_ctx* ctx, int n_pairs, const float* d_R, con
                                int width, int height, float* d_M);
 int nsof_stage_blur_solve(nsof_ctx* ctx, int n_pairs, const float* d_M, int width, int height,
                           int winsize, float* d_flow);
+/* One fused Farneback iteration (matrix update + blur + solve): flow_out = step(R, flow_in).  d_flow_in and
+ * d_flow_out must not alias.  winsize 2..17; larger windows take the unfused pair above. */
+int nsof_stage_iterate(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_flow_in, int width, int height,
+                       int winsize, float* d_flow_out);
 int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* d_src, int src_w, int src_h,
                              float* d_dst, int dst_w, int dst_h, double pyr_scale);
 
@@ -105,7 +109,8 @@ typedef enum nsof_kernel_id {
     NSOF_K_UPDMAT = 3,      /* matrix update with warped R1 */
     NSOF_K_BLUR = 4,        /* box blur + 2x2 solve */
     NSOF_K_ACCUM = 5,       /* accumulator state update */
-    NSOF_K_COUNT = 6
+    NSOF_K_ITERATE = 6,     /* fused matrix update + box blur + solve (one Farneback iteration) */
+    NSOF_K_COUNT = 7
 } nsof_kernel_id;
 /* mask: bit (1<<id) enables event bracketing for that kernel; 0 disables. */
 int nsof_prof_enable(nsof_ctx* ctx, unsigned mask);

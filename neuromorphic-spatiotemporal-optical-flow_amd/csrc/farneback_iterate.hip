@@ -1,0 +1,587 @@
+// Farneback inner iteration, fused: matrix update (warped R1) + box blur + 2x2 solve in ONE kernel.
+//
+// Reference arithmetic: FarnebackUpdateMatrices followed by FarnebackUpdateFlow_Blur of the library behind
+// cv2.calcOpticalFlowFarneback (/root/reference/optical_flow_seg.py:203).  The unfused pair of kernels
+// (k_update_matrices + k_blur_solve) moves 68 + 28 = 96 B/px per iteration through HBM because the
+// 5-plane matrix M is written and read back.  Here M never leaves the CU:
+//
+//   * a 256-thread block owns a strip of 256 image columns (SW outputs + m halo columns per side) and
+//     walks down the full image height two rows per step -- the column sums are running sums from row 0
+//     (each row adds double(float(M[y+m] - M[y-m-1])): the float rounding of that difference is part of the
+//     reference arithmetic), so rows must be visited in order;
+//   * thread <-> column computes M for the incoming row (bilinear gather of R1 at x+flow) and keeps the
+//     last 2m+2 rows of M of its column in a REGISTER ring (static slots: the row loop is unrolled over
+//     one ring period), plus the 5 double column sums;
+//   * the R0/R1 loads of the next step (2 rows) and the flow two steps ahead are in flight while the current
+//     step computes (one wave keeps ~34 loads outstanding);
+//   * column sums go to LDS (20 KB); thread <-> 2 adjacent pixels forms the row sums and solves.
+//
+// HBM traffic per pixel per iteration: R0 20 + R1 ~20 + flow 8 read, flow 8 written = 56 B (+ halo).
+#include <cstdlib>
+
+#include "nsof_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int floor_f(float v)
+{
+    int i = (int)v;
+    return i - (i > v);
+}
+
+// 32-bit byte offsets against wave-uniform plane bases keep every load in the
+// "SGPR base + VGPR offset" form (no 64-bit address arithmetic in VGPRs).
+struct Planes {
+    const char* p[5];
+};
+struct __attribute__((packed, aligned(4))) f2u {  // two adjacent floats, only 4-byte aligned
+    float a, b;
+};
+__device__ __forceinline__ float ldf(const char* base, unsigned boff)
+{
+    return *reinterpret_cast<const float*>(base + boff);
+}
+__device__ __forceinline__ f2u ldf2(const char* base, unsigned boff)
+{
+#ifdef NSOF_GATHER_DWORD
+    f2u r;   // two dword loads instead of one 4-byte-aligned dwordx2 (kept apart from the load combiner)
+    unsigned b2 = boff + 4u;
+    asm volatile("" : "+v"(b2));
+    r.a = *reinterpret_cast<const float*>(base + boff);
+    r.b = *reinterpret_cast<const float*>(base + b2);
+    return r;
+#else
+    return *reinterpret_cast<const f2u*>(base + boff);
+#endif
+}
+
+struct RowIn {
+    float r0[5];
+    f2u top[5], bot[5];   // R1 at (y1, x1..x1+1) and (y1+1, x1..x1+1)
+    float dx, dy, fx, fy;
+    int inside;
+};
+
+// Issue every load one (row, column) needs; `d` is the flow at that pixel (already loaded).
+__device__ __forceinline__ void issue_row(RowIn& in, const Planes& R0, const Planes& R1, int W, int H, int x, int y,
+                                          float2 d)
+{
+    const unsigned pix = ((unsigned)y * (unsigned)W + (unsigned)x) * 4u;
+    in.dx = d.x;
+    in.dy = d.y;
+    float fx = x + d.x, fy = y + d.y;
+    const int x1 = floor_f(fx), y1 = floor_f(fy);
+    in.fx = fx - x1;
+    in.fy = fy - y1;
+    in.inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
+#if defined(NSOF_ABL) && NSOF_ABL == 3   // timing-only build: no R0 loads either
+#pragma unroll
+    for (int c = 0; c < 5; c++) in.r0[c] = d.x * (float)(c + 1) + (float)pix;
+#else
+#pragma unroll
+    for (int c = 0; c < 5; c++) in.r0[c] = ldf(R0.p[c], pix);
+#endif
+    // The R1 gather is issued unconditionally, at a clamped (always valid) address when the sample falls
+    // outside: a load under a lane-dependent branch cannot be counted by s_waitcnt vmcnt(N), which would
+    // force every wait down to "almost nothing outstanding" and serialise the software pipeline.
+    const int xs = clampi(x1, 0, W - 2), ys = clampi(y1, 0, H - 2);
+    const unsigned o = ((unsigned)ys * (unsigned)W + (unsigned)xs) * 4u;
+#if defined(NSOF_ABL) && (NSOF_ABL == 1 || NSOF_ABL == 3)   // timing-only build: no R1 gather
+#pragma unroll
+    for (int c = 0; c < 5; c++) { in.top[c].a = in.top[c].b = in.bot[c].a = in.bot[c].b = in.r0[c] + (float)o; }
+#else
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        in.top[c] = ldf2(R1.p[c], o);
+        in.bot[c] = ldf2(R1.p[c], o + (unsigned)W * 4u);
+    }
+#endif
+}
+
+// FarnebackUpdateMatrices for one pixel, from loaded inputs.
+__device__ __forceinline__ void matrix_from(const RowIn& in, int x, int y, int W, int H, float (&M)[5])
+{
+    float r2, r3, r4, r5, r6;
+    const float dx = in.dx, dy = in.dy;
+    if (in.inside) {
+        const float fx = in.fx, fy = in.fy;
+        const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        r2 = a00 * in.top[0].a + a01 * in.top[0].b + a10 * in.bot[0].a + a11 * in.bot[0].b;
+        r3 = a00 * in.top[1].a + a01 * in.top[1].b + a10 * in.bot[1].a + a11 * in.bot[1].b;
+        r4 = a00 * in.top[2].a + a01 * in.top[2].b + a10 * in.bot[2].a + a11 * in.bot[2].b;
+        r5 = a00 * in.top[3].a + a01 * in.top[3].b + a10 * in.bot[3].a + a11 * in.bot[3].b;
+        r6 = a00 * in.top[4].a + a01 * in.top[4].b + a10 * in.bot[4].a + a11 * in.bot[4].b;
+        r4 = (in.r0[2] + r4) * 0.5f;
+        r5 = (in.r0[3] + r5) * 0.5f;
+        r6 = (in.r0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = in.r0[2];
+        r5 = in.r0[3];
+        r6 = in.r0[4] * 0.5f;
+    }
+    r2 = (in.r0[0] - r2) * 0.5f;
+    r3 = (in.r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10)) {
+        auto bw = [](int i) { return i < 2 ? 0.14f : 0.4472f; };
+        const float scale = (x < 5 ? bw(x) : 1.f) * (x >= W - 5 ? bw(W - x - 1) : 1.f) * (y < 5 ? bw(y) : 1.f) *
+                            (y >= H - 5 ? bw(H - y - 1) : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
+template <int MH>
+struct IterGeom {
+    static constexpr int RB = 2;                               // rows per step (4 spills the register ring)
+    static constexpr int RING = 2 * MH + 2;                    // rows a column sum spans + the one leaving
+    static constexpr int SW = (256 - 2 * MH) & ~1;             // output columns per block (a thread owns 2 pixels)
+};
+
+template <int MH>
+__global__ __launch_bounds__(256, 2) void k_iterate(const float* __restrict__ R0b, const float* __restrict__ R1b,
+                                                     size_t pair_stride, const float* __restrict__ flow_in,
+                                                     float* __restrict__ flow_out, int W, int H, int block_size)
+{
+    using G = IterGeom<MH>;
+    constexpr int RING = G::RING, SW = G::SW, RB = G::RB;
+    __shared__ double sv[RB][5][256];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * SW;
+    const int xc = clampi(x0 - MH + tid, 0, W - 1);
+    const size_t plane = (size_t)W * H;
+    Planes R0, R1;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        R0.p[c] = reinterpret_cast<const char*>(R0b + (size_t)blockIdx.z * pair_stride + c * plane);
+        R1.p[c] = reinterpret_cast<const char*>(R1b + (size_t)blockIdx.z * pair_stride + c * plane);
+    }
+    const char* FinB = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * plane * 8;
+    auto flowAt = [&](int r) {   // flow_in at (row r, this thread's column)
+        return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
+    };
+    float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)blockIdx.z * plane;
+    const double scale = 1. / (block_size * block_size);
+    auto rowOf = [&](int i) { return min(i, H - 1); };   // stream index -> image row (replicated bottom)
+
+    // ---- prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0
+    float ring[RING][5];
+    double vs[5];
+    {
+        RowIn in;
+        float M0[5];
+        issue_row(in, R0, R1, W, H, xc, 0, flowAt(0));
+        matrix_from(in, xc, 0, W, H, M0);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            vs[c] = (double)(M0[c] * (float)(MH + 2));   // float product, as "srow0[x]*(m+2)"
+#pragma unroll
+            for (int j = 0; j < RING; j++) ring[j][c] = M0[c];   // slots of rows -m-1..-1 (and 0) hold row 0
+        }
+#pragma unroll
+        for (int i = 1; i < MH; i++) {
+            float Mi[5];
+            const int r = rowOf(i);
+            issue_row(in, R0, R1, W, H, xc, r, flowAt(r));
+            matrix_from(in, xc, r, W, H, Mi);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c] += (double)Mi[c];
+                ring[i][c] = Mi[c];
+            }
+        }
+    }
+    // ---- software pipeline: R loads one step (4 rows) ahead, flow two steps ahead
+    RowIn in[RB];
+    float2 fnext[RB];
+#pragma unroll
+    for (int q = 0; q < RB; q++) {
+        const int r = rowOf(MH + q);
+        issue_row(in[q], R0, R1, W, H, xc, r, flowAt(r));
+        fnext[q] = flowAt(rowOf(MH + RB + q));
+    }
+
+    for (int yb = 0; yb < H; yb += RING) {
+#pragma unroll
+        for (int s = 0; s < RING / RB; s++) {
+            const int y = yb + RB * s;
+            if (y >= H) break;
+#pragma unroll
+            for (int q = 0; q < RB; q++) {
+                const int i = y + MH + q;                       // stream index of the row entering the window
+                const int slot_new = (RB * s + q + MH) % RING;
+                const int slot_old = (RB * s + q + 2 * RING - MH - 1) % RING;
+                float Mn[5];
+                matrix_from(in[q], xc, rowOf(i), W, H, Mn);
+                // refill the pipeline: this slot now loads row i+RB; its flow was fetched a step ago
+                issue_row(in[q], R0, R1, W, H, xc, rowOf(i + RB), fnext[q]);
+                fnext[q] = flowAt(rowOf(i + 2 * RB));
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const float d = Mn[c] - ring[slot_old][c];
+                    vs[c] += (double)d;
+                    ring[slot_new][c] = Mn[c];
+                    sv[q][c][tid] = vs[c];
+                }
+            }
+            __syncthreads();
+            const int hrow = tid >> 7, t = tid & 127;   // 128 threads per row, 2 pixels each
+            const int yo = y + hrow, xo = x0 + 2 * t;
+            if (2 * t < SW && yo < H && xo < W) {
+                double g[5];
+                float2 o[2];
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    if (p == 0) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) {
+                            double a = 0;
+#pragma unroll
+                            for (int j = 0; j <= 2 * MH; j++) a += sv[hrow][c][2 * t + j];
+                            g[c] = a;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) g[c] += sv[hrow][c][2 * t + 1 + 2 * MH] - sv[hrow][c][2 * t];
+                    }
+                    const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+                    const double h1 = g[3] * scale, h2 = g[4] * scale;
+                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
+                    o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
+                }
+                float2* dst = Fout + (size_t)yo * W + xo;
+                dst[0] = o[0];
+                if (xo + 1 < W) dst[1] = o[1];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Role-specialised variant (the one the driver uses): 768 threads = 12 waves per strip, one block per CU.
+//
+// The plain walker above is limited by registers (the M ring and the loads in flight compete for one
+// thread's budget) and by code size (static ring slots force unrolling a whole ring period).  Here:
+//   waves 0-3   consumers  thread <-> column: the 5 double column sums in registers; row sums + solve
+//   waves 4-7   producers A, waves 8-11 producers B: stateless; thread <-> column computes M for the two rows
+//               of every other step and keeps the R0/R1 loads of its next TWO steps in flight
+//               -> 8 rows of loads in flight per column.
+// M rows go from producers to consumers through a ring in LDS (2m+6 rows x 5 planes x 256 columns,
+// 100 KB for winsize 15) that also serves as the window history (M[y-m-1] is read back from it), indexed
+// dynamically -- no unrolling.  ONE block barrier per 2-row step (the column sums are double-buffered), and the
+// producers' gather for step s+2 overlaps the consumers' row sums + solve of step s.  Arithmetic and its order are identical
+// to k_iterate / the unfused kernels.
+// ---------------------------------------------------------------------------------------------
+template <int MH, int COLS>
+struct PCGeom {
+    static constexpr int RL = 2 * MH + 6;                   // ring rows: window 2m+1, the leaving row, 2 being
+                                                            // consumed next, 2 being produced
+    static constexpr int SW = (COLS - 2 * MH) & ~1;         // output columns per block
+    static constexpr size_t SMEM = sizeof(double) * 4 * 5 * COLS + sizeof(float) * RL * 5 * COLS;
+};
+
+// Producer group G produces step t (rows 2t+m, 2t+m+1 of the stream) from the loads in in[J].
+template <int MH, int COLS, int J>
+__device__ __forceinline__ void produce_step(RowIn (&in)[2][2], float2 (&fl)[2], float (*mring)[5][COLS],
+                                             const Planes& R0, const Planes& R1, const char* FinB, int W, int H,
+                                             int xc, int col, int t)
+{
+    constexpr int RL = PCGeom<MH, COLS>::RL;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int i = 2 * t + MH + q;
+        float Mn[5];
+        matrix_from(in[J][q], xc, min(i, H - 1), W, H, Mn);
+        const int slot = (i + MH + 1) % RL;      // stream index -MH-1 (first replicated row) lives in slot 0
+#pragma unroll
+        for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
+        // refill: my step after next is t + 4; its flow was fetched when I produced t - 2
+        issue_row(in[J][q], R0, R1, W, H, xc, min(i + 8, H - 1), fl[q]);
+        fl[q] = *reinterpret_cast<const float2*>(FinB + ((unsigned)min(i + 12, H - 1) * (unsigned)W + (unsigned)xc) * 8u);
+    }
+}
+
+// Producer waves of group G: their own loop, with exactly the same barrier sequence as the consumers.
+template <int MH, int COLS, int G>
+__device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Planes& R0, const Planes& R1,
+                                              const char* FinB, int W, int H, int xc, int col, int nsteps)
+{
+    RowIn in[2][2];
+    float2 fl[2];
+    auto flowAt = [&](int r) {
+        return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
+    };
+    // my steps are G, G+2, G+4, ...; two of them in flight
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int r = min(2 * (G + 2 * j) + MH + q, H - 1);
+            issue_row(in[j][q], R0, R1, W, H, xc, r, flowAt(r));
+        }
+#pragma unroll
+    for (int q = 0; q < 2; q++) fl[q] = flowAt(min(2 * (G + 4) + MH + q, H - 1));
+    // Barrier sequence (identical in all roles): B_init, then B(s) for s = 0..nsteps-1.
+    //   before B_init            group 0 produces step 0
+    //   between B_init and B(0)  group 1 produces step 1            (consumers: column sums of step 0)
+    //   between B(s) and B(s+1)  group s&1 produces step s+2        (consumers: row sums + solve of step s,
+    //                                                                 column sums of step s+1)
+    // In the 4-step period starting at sb: s=sb -> G0 slot 1, sb+1 -> G1 slot 1, sb+2 -> G0 slot 0, sb+3 -> G1 slot 0.
+    if (G == 0) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 0);
+    __syncthreads();
+    if (G == 1) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 1);
+    for (int sb = 0; sb < nsteps; sb += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int s = sb + u;
+            if (s >= nsteps) break;
+            __syncthreads();
+            if (G == 0 && u == 0) produce_step<MH, COLS, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (G == 1 && u == 1) produce_step<MH, COLS, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (G == 0 && u == 2) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (G == 1 && u == 3) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+        }
+    }
+}
+
+template <int MH, int COLS>
+__device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
+                                              const Planes& R1, const char* FinB, float2* Fout, int W, int H, int x0,
+                                              int xc, int col, int nsteps, double scale)
+{
+    using G = PCGeom<MH, COLS>;
+    constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
+    double vs[5];
+    auto flowAt = [&](int r) {
+        return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
+    };
+    {
+        // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
+        // ring slot of stream index i is (i + m + 1) % RL.
+        RowIn t;
+        float M0[5];
+        issue_row(t, R0, R1, W, H, xc, 0, flowAt(0));
+        matrix_from(t, xc, 0, W, H, M0);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            vs[c] = (double)(M0[c] * (float)(MH + 2));   // float product, as "srow0[x]*(m+2)"
+#pragma unroll
+            for (int j = 0; j <= MH + 1; j++) mring[j][c][col] = M0[c];   // stream indices -m-1 .. 0
+        }
+#pragma unroll
+        for (int i = 1; i < MH; i++) {
+            float Mi[5];
+            const int r = min(i, H - 1);
+            issue_row(t, R0, R1, W, H, xc, r, flowAt(r));
+            matrix_from(t, xc, r, W, H, Mi);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c] += (double)Mi[c];
+                mring[i + MH + 1][c][col] = Mi[c];
+            }
+        }
+    }
+    __syncthreads();   // B_init: step 0 is in the ring
+    const int hrow = col / HT, t = col % HT;
+    int slot_new = (2 * MH + 1) % RL;           // stream index m   -> slot 2m+1
+    int slot_old = 0;                           // stream index -m-1 -> slot 0
+    auto column_sums = [&](int buf) {           // two more rows enter the window of this thread's column
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
+                vs[c] += (double)d;
+                sv[2 * buf + q][c][col] = vs[c];
+            }
+            slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
+            slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
+        }
+    };
+    column_sums(0);
+    for (int s = 0; s < nsteps; s++) {
+        __syncthreads();   // B(s): column sums of step s visible; rows of step s+1 are in the ring
+        const int buf = s & 1;
+        const int yo = 2 * s + hrow, xo = x0 + 2 * t;
+#if defined(NSOF_ABL) && NSOF_ABL == 2   // timing-only build: no row sums / solve
+        if (2 * t < SW && yo < H && xo < W) {
+            float2* dst = Fout + (size_t)yo * W + xo;
+            dst[0] = make_float2((float)sv[2 * buf + hrow][0][2 * t], (float)sv[2 * buf + hrow][1][2 * t]);
+            if (xo + 1 < W) dst[1] = make_float2((float)sv[2 * buf + hrow][2][2 * t + 1], (float)sv[2 * buf + hrow][3][2 * t + 1]);
+        }
+#else
+        if (2 * t < SW && yo < H && xo < W) {
+            const double (*svr)[COLS] = sv[2 * buf + hrow];
+            double g[5];
+            float2 o[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                if (p == 0) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        double a = 0;
+#pragma unroll
+                        for (int j = 0; j <= 2 * MH; j++) a += svr[c][2 * t + j];
+                        g[c] = a;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) g[c] += svr[c][2 * t + 1 + 2 * MH] - svr[c][2 * t];
+                }
+                const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+                const double h1 = g[3] * scale, h2 = g[4] * scale;
+                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
+                o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+            float2* dst = Fout + (size_t)yo * W + xo;
+            dst[0] = o[0];
+            if (xo + 1 < W) dst[1] = o[1];
+        }
+#endif
+        // column sums of the next step go to the other buffer: no barrier needed in between
+        if (s + 1 < nsteps) column_sums(buf ^ 1);
+    }
+}
+
+template <int MH, int COLS>
+__global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict__ R0b, const float* __restrict__ R1b,
+                                                     size_t pair_stride, const float* __restrict__ flow_in,
+                                                     float* __restrict__ flow_out, int W, int H, int block_size)
+{
+    constexpr int SW = PCGeom<MH, COLS>::SW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
+    double (*sv)[5][COLS] = reinterpret_cast<double (*)[5][COLS]>(smem_pc);   // [2 buffers x 2 rows][5][COLS]
+    float (*mring)[5][COLS] = reinterpret_cast<float (*)[5][COLS]>(smem_pc + sizeof(double) * 4 * 5 * COLS);  // [RL]
+
+    const int tid = threadIdx.x, col = tid % COLS;
+    const int role = __builtin_amdgcn_readfirstlane(tid / COLS);   // wave-uniform: 0 consumer, 1/2 producers
+    const int x0 = blockIdx.x * SW;
+    const int xc = clampi(x0 - MH + col, 0, W - 1);
+    const size_t plane = (size_t)W * H;
+    Planes R0, R1;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        R0.p[c] = reinterpret_cast<const char*>(R0b + (size_t)blockIdx.z * pair_stride + c * plane);
+        R1.p[c] = reinterpret_cast<const char*>(R1b + (size_t)blockIdx.z * pair_stride + c * plane);
+    }
+    const char* FinB = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * plane * 8;
+    float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)blockIdx.z * plane;
+    const int nsteps = (H + 1) / 2;
+    // Each role runs its own loop; all three execute one barrier before the loop and two per step.
+    if (role == 0)
+        consumer_loop<MH, COLS>(mring, sv, R0, R1, FinB, Fout, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
+    else if (role == 1)
+        producer_loop<MH, COLS, 0>(mring, R0, R1, FinB, W, H, xc, col, nsteps);
+    else
+        producer_loop<MH, COLS, 1>(mring, R0, R1, FinB, W, H, xc, col, nsteps);
+}
+
+template <int MH, int COLS>
+void launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                         const float* flow_in, float* flow_out, int W, int H, int winsize)
+{
+    using G = PCGeom<MH, COLS>;
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in attribute (once per kernel)
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_iterate_pc<MH, COLS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
+        attr_set = true;
+    }
+    dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
+    hipLaunchKernelGGL((k_iterate_pc<MH, COLS>), grid, dim3(3 * COLS), G::SMEM, ctx->stream, R0, R1, pair_stride,
+                       flow_in, flow_out, W, H, winsize);
+}
+
+static int pc_cols()
+{
+    static int cols = 0;
+    if (!cols) {
+        const char* e = getenv("NSOF_PC_COLS");   // tuning knob: strip width of the role-specialised kernel
+        cols = e ? atoi(e) : 256;
+        if (cols != 64 && cols != 128 && cols != 256) cols = 256;
+    }
+    return cols;
+}
+
+template <int MH>
+void launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                       const float* flow_in, float* flow_out, int W, int H, int winsize)
+{
+    switch (pc_cols()) {
+        case 64: launch_iterate_pc_c<MH, 64>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 128: launch_iterate_pc_c<MH, 128>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        default: launch_iterate_pc_c<MH, 256>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+    }
+}
+
+template <int MH>
+void launch_iterate_m(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                      const float* flow_in, float* flow_out, int W, int H, int winsize)
+{
+    constexpr int SW = IterGeom<MH>::SW;
+    dim3 grid((W + SW - 1) / SW, 1, n_pairs);
+    hipLaunchKernelGGL(k_iterate<MH>, grid, dim3(256), 0, ctx->stream, R0, R1, pair_stride, flow_in, flow_out, W, H,
+                       winsize);
+}
+
+}  // namespace
+
+bool nsof_iterate_supported(int winsize, int W, int H)
+{
+    const int m = winsize / 2;
+    return m >= 1 && m <= 8 && W >= 2 && H >= 2;   // the clamped gather needs a 2x2 neighbourhood to exist
+}
+
+static int g_iterate_variant = -1;   // NSOF_ITERATE=walker|pc (tuning / A-B runs); default pc
+static bool use_pc(int m)
+{
+    if (g_iterate_variant < 0) {
+        const char* e = getenv("NSOF_ITERATE");
+        g_iterate_variant = (e && e[0] == 'w') ? 0 : 1;
+    }
+    return g_iterate_variant == 1 && m <= 7;
+}
+
+// flow_in and flow_out must be different buffers (rows y+m of flow_in are read while row y of flow_out is written).
+int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                        const float* flow_in, float* flow_out, int W, int H, int winsize)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    if (use_pc(winsize / 2)) {
+        switch (winsize / 2) {
+            case 1: launch_iterate_pc<1>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+            case 2: launch_iterate_pc<2>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+            case 3: launch_iterate_pc<3>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+            case 4: launch_iterate_pc<4>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+            case 5: launch_iterate_pc<5>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+            case 6: launch_iterate_pc<6>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+            default: launch_iterate_pc<7>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        }
+        NSOF_HIP(ctx, hipGetLastError());
+        return NSOF_OK;
+    }
+    switch (winsize / 2) {
+        case 1: launch_iterate_m<1>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 2: launch_iterate_m<2>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 3: launch_iterate_m<3>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 4: launch_iterate_m<4>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 5: launch_iterate_m<5>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 6: launch_iterate_m<6>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 7: launch_iterate_m<7>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        case 8: launch_iterate_m<8>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "fused iteration supports winsize 2..17");
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}

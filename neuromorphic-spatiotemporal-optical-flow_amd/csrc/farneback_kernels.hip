@@ -217,29 +217,39 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 {
     using G = PolyGeom<N>;
     __shared__ __attribute__((aligned(16))) float sr[2][3][4][256];
+    // The 2N double-precision taps would not fit the scalar register file next to the float taps (SGPR
+    // spills cost more than the arithmetic); they live in LDS and are re-read (broadcast) once per step.
+    __shared__ double stap[2][N + 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid <= N) {
+        stap[0][tid] = tp.dg[tid];
+        stap[1][tid] = tp.dxxg[tid];
+    }
     const int x0 = blockIdx.x * G::SW;
     const int ys = blockIdx.y * seg_rows, ye = min(ys + seg_rows, H);
-    const size_t plane = (size_t)W * H;
-    const float* I = img + (size_t)blockIdx.z * plane;
-    float* Rz = R + (size_t)blockIdx.z * 5 * plane;
+    const unsigned plane = (unsigned)W * (unsigned)H;
+    // wave-uniform bases + 32-bit byte offsets: loads/stores stay in "SGPR base + VGPR offset" form
+    const char* Ib = reinterpret_cast<const char*>(img + (size_t)blockIdx.z * plane);
+    char* Rb = reinterpret_cast<char*>(R + (size_t)blockIdx.z * 5 * plane);
     const int xc = clampi(x0 - G::NP + tid, 0, W - 1);
-    const float* Ic = I + xc;
+    auto ld = [&](int row) {
+        return *reinterpret_cast<const float*>(Ib + ((unsigned)clampi(row, 0, H - 1) * (unsigned)W + (unsigned)xc) * 4u);
+    };
 
     // register window: win[j] = I[clamp(y - N + j)][xc]
     float win[2 * N + 1];
 #pragma unroll
-    for (int j = 0; j <= 2 * N; j++) win[j] = Ic[(size_t)clampi(ys - N + j, 0, H - 1) * W];
+    for (int j = 0; j <= 2 * N; j++) win[j] = ld(ys - N + j);
     float pre[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) pre[q] = Ic[(size_t)clampi(ys + 1 + N + q, 0, H - 1) * W];
+    for (int q = 0; q < 4; q++) pre[q] = ld(ys + 1 + N + q);
 
     int buf = 0;
     for (int y = ys; y < ye; y += 4, buf ^= 1) {
         float nxt[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) nxt[q] = Ic[(size_t)clampi(y + 5 + N + q, 0, H - 1) * W];
+        for (int q = 0; q < 4; q++) nxt[q] = ld(y + 5 + N + q);
 
         // ---- vertical pass: 4 rows for this thread's column
 #pragma unroll
@@ -265,19 +275,41 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
         for (int q = 0; q < 4; q++) pre[q] = nxt[q];
         __syncthreads();
 
-        // ---- horizontal pass: wave <-> row, lane <-> 4 pixels
+        // ---- horizontal pass: wave <-> row, lane <-> 4 pixels; each moment row is consumed and its
+        //      outputs stored before the next one is read (keeps the live register set small)
         const int yo = y + wave;
         const int xo = x0 + 4 * lane;
         if (4 * lane < G::SW && yo < ye && xo < W) {
-            double b1[4], b2[4], b3[4], b4[4], b5[4], b6[4];
-            {
-                float v[4 * G::NV];
-                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][0][wave][4 * lane]);
+            const unsigned obase = ((unsigned)yo * (unsigned)W + (unsigned)xo) * 4u;
+            const bool vec = (W & 3) == 0;
+            auto store4 = [&](int c, const float (&o)[4]) {
+                char* dst = Rb + (obase + (unsigned)c * plane * 4u);
+                if (vec) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (xo + p < W) reinterpret_cast<float*>(dst)[p] = o[p];
+                }
+            };
+            auto load_row = [&](int a, float (&v)[4 * G::NV]) {
+                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][a][wave][4 * lane]);
 #pragma unroll
                 for (int i = 0; i < G::NV; i++) {
-                    float4 f = p4[i];
+                    const float4 f = p4[i];
                     v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
                 }
+            };
+            double t03[4];  // b1 * ig03, shared by the xx and yy outputs
+            {
+                float v[4 * G::NV], o1[4], o3[4];
+                double dg[N + 1], dxxg[N + 1];
+#pragma unroll
+                for (int k = 1; k <= N; k++) {
+                    dg[k] = stap[0][k];
+                    dxxg[k] = stap[1][k];
+                }
+                load_row(0, v);
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int c = G::NP + p;
@@ -286,21 +318,20 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                     for (int k = 1; k <= N; k++) {
                         const float hi = v[c + k], lo = v[c - k];
                         const double tg = (double)(hi + lo);
-                        a1 = fma(tg, tp.dg[k], a1);     // product of two float-valued doubles is exact
-                        a4 = fma(tg, tp.dxxg[k], a4);
+                        a1 = fma(tg, dg[k], a1);     // product of two float-valued doubles is exact
+                        a4 = fma(tg, dxxg[k], a4);
                         a2 += (double)((hi - lo) * tp.xg[k]);
                     }
-                    b1[p] = a1; b2[p] = a2; b4[p] = a4;
+                    t03[p] = a1 * tp.ig03;
+                    o1[p] = (float)(a2 * tp.ig11);
+                    o3[p] = (float)(t03[p] + a4 * tp.ig33);
                 }
+                store4(1, o1);
+                store4(3, o3);
             }
             {
-                float v[4 * G::NV];
-                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][1][wave][4 * lane]);
-#pragma unroll
-                for (int i = 0; i < G::NV; i++) {
-                    float4 f = p4[i];
-                    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
-                }
+                float v[4 * G::NV], o0[4], o4[4];
+                load_row(1, v);
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int c = G::NP + p;
@@ -311,46 +342,24 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                         a3 += (double)((hi + lo) * tp.g[k]);
                         a6 += (double)((hi - lo) * tp.xg[k]);
                     }
-                    b3[p] = a3; b6[p] = a6;
+                    o0[p] = (float)(a3 * tp.ig11);
+                    o4[p] = (float)(a6 * tp.ig55);
                 }
+                store4(0, o0);
+                store4(4, o4);
             }
             {
-                float v[4 * G::NV];
-                const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][2][wave][4 * lane]);
-#pragma unroll
-                for (int i = 0; i < G::NV; i++) {
-                    float4 f = p4[i];
-                    v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
-                }
+                float v[4 * G::NV], o2[4];
+                load_row(2, v);
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int c = G::NP + p;
                     double a5 = (double)(v[c] * tp.g[0]);
 #pragma unroll
                     for (int k = 1; k <= N; k++) a5 += (double)((v[c + k] + v[c - k]) * tp.g[k]);
-                    b5[p] = a5;
+                    o2[p] = (float)(t03[p] + a5 * tp.ig33);
                 }
-            }
-            float o[5][4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                o[0][p] = (float)(b3[p] * tp.ig11);
-                o[1][p] = (float)(b2[p] * tp.ig11);
-                o[2][p] = (float)(b1[p] * tp.ig03 + b5[p] * tp.ig33);
-                o[3][p] = (float)(b1[p] * tp.ig03 + b4[p] * tp.ig33);
-                o[4][p] = (float)(b6[p] * tp.ig55);
-            }
-            float* dst = Rz + (size_t)yo * W + xo;
-            if ((W & 3) == 0) {
-#pragma unroll
-                for (int c = 0; c < 5; c++)
-                    *reinterpret_cast<float4*>(dst + c * plane) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 5; c++)
-#pragma unroll
-                    for (int p = 0; p < 4; p++)
-                        if (xo + p < W) dst[c * plane + p] = o[c][p];
+                store4(2, o2);
             }
         }
         // no second barrier: the next step writes the other LDS buffer

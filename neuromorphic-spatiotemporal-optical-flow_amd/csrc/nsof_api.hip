@@ -88,7 +88,7 @@ extern "C" int nsof_prof_collect(nsof_ctx* ctx, int id, double* total_ms, long l
 extern "C" const char* nsof_kernel_name(int id)
 {
     static const char* names[NSOF_K_COUNT] = {"prep", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
-                                              "accum_update"};
+                                              "accum_update", "iterate"};
     return (id >= 0 && id < NSOF_K_COUNT) ? names[id] : "?";
 }
 
@@ -355,6 +355,17 @@ extern "C" int nsof_stage_blur_solve(nsof_ctx* ctx, int n_pairs, const float* d_
     return nsof_launch_blur_solve(ctx, n_pairs, d_M, width, height, winsize, d_flow);
 }
 
+extern "C" int nsof_stage_iterate(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_flow_in, int width,
+                                  int height, int winsize, float* d_flow_out)
+{
+    if (!ctx || !d_R || !d_flow_in || !d_flow_out || d_flow_in == d_flow_out || n_pairs < 1 || width < 1 || height < 1)
+        return NSOF_EINVAL;
+    if (!nsof_iterate_supported(winsize, width, height)) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "winsize %d not fused", winsize);
+    const size_t plane = (size_t)width * height;
+    return nsof_launch_iterate(ctx, n_pairs, d_R, d_R + 5 * plane, 10 * plane, d_flow_in, d_flow_out, width, height,
+                               winsize);
+}
+
 extern "C" int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* d_src, int sw, int sh, float* d_dst,
                                         int dw, int dh, double pyr_scale)
 {
@@ -381,25 +392,29 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
     if ((rc = nsof_host_poly_taps(poly_n, poly_sigma, &ptaps))) return nsof_set_error(ctx, rc, "poly taps");
     const int L = nsof_farneback_effective_levels(width, height, pyr_scale, levels);
 
-    // workspace: I [B][2][n0], R [B][2][5][n0], M [B][5][n0], coarse flow ping/pong [B][n1][2]
+    // workspace: I [2][B][n0] f32, R [2][B][5][n0] f32, S = second flow buffer [B][n0][2]
+    // (+ M [B][5][n0] only when the window is too large for the fused iteration kernel)
     const size_t n0 = (size_t)width * height, B = (size_t)n_pairs;
-    size_t n1 = 0;
-    if (L >= 1) {
-        int w1, h1;
-        nsof_farneback_level_size(width, height, pyr_scale, 1, &w1, &h1, nullptr, nullptr);
-        n1 = (size_t)w1 * h1;
-    }
+    // decided once for the whole pyramid (the coarsest level is never smaller than 2x2 when min_size is 32;
+    // tiny inputs whose level 0 is below 2x2 take the unfused pair)
+    const bool fused = nsof_iterate_supported(winsize, width, height);
     const size_t szI = align_up(B * 2 * n0 * 4, 256), szR = align_up(B * 10 * n0 * 4, 256);
-    const size_t szM = align_up(B * 5 * n0 * 4, 256), szF = align_up(B * n1 * 8, 256);
-    if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szM + 2 * szF))) return rc;
+    const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
+    if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM))) return rc;
     char* base = (char*)ctx->ws;
     float* dI = (float*)base;
     float* dR = (float*)(base + szI);
-    float* dM = (float*)(base + szI + szR);
-    float* dF[2] = {(float*)(base + szI + szR + szM), (float*)(base + szI + szR + szM + szF)};
+    float* dS = (float*)(base + szI + szR);
+    float* dM = (float*)(base + szI + szR + szS);
+    // Two flow buffers, A = the caller's output and S = scratch; every level uses their leading B*nk pixels.
+    // Each upsample and each fused iteration moves the flow to the other buffer, so the buffer the coarsest
+    // level starts in is chosen such that the last iteration of level 0 writes A.
+    float* fb[2] = {d_flow, dS};
+    const int flips = fused ? L * (1 + iterations) + iterations : L;
+    int cur = flips & 1;
 
-    const float* prev_flow = nullptr;
-    int pw = 0, ph = 0, pp = 0;
+    bool have_prev = false;
+    int pw = 0, ph = 0;
     for (int k = L; k >= 0; k--) {
         int wk, hk, ks;
         double sg;
@@ -409,13 +424,13 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
             return nsof_set_error(ctx, rc, "pyramid blur kernel size %d unsupported (max %d)", ks,
                                   NSOF_MAX_BLUR_TAPS - 1);
         const size_t nk = (size_t)wk * hk;
-        float* flow = (k == 0) ? d_flow : dF[pp];
-        if (!prev_flow) {
-            NSOF_HIP(ctx, hipMemsetAsync(flow, 0, B * nk * 8, ctx->stream));
+        if (!have_prev) {
+            NSOF_HIP(ctx, hipMemsetAsync(fb[cur], 0, B * nk * 8, ctx->stream));
         } else {
-            if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, prev_flow, pw, ph, flow, wk, hk,
+            if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, fb[cur], pw, ph, fb[cur ^ 1], wk, hk,
                                                 (float)(1. / pyr_scale))))
                 return rc;
+            cur ^= 1;
         }
         // image-major batches: dI [2][B][hk][wk] (all prev frames, then all next frames),
         // dR [2][B][5][hk][wk]; one prep launch per frame set, one polyexp launch for all 2B images.
@@ -426,17 +441,27 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
         if ((rc = nsof_launch_polyexp(ctx, 2 * n_pairs, dI, wk, hk, ptaps, dR))) return rc;
         const float* R0 = dR;
         const float* R1 = dR + B * 5 * nk;
-        if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
-        for (int it = 0; it < iterations; it++) {
-            if ((rc = nsof_launch_blur_solve(ctx, n_pairs, dM, wk, hk, winsize, flow))) return rc;
-            if (it < iterations - 1)
-                if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
+        if (fused) {
+            for (int it = 0; it < iterations; it++) {
+                if ((rc = nsof_launch_iterate(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize)))
+                    return rc;
+                cur ^= 1;
+            }
+        } else {
+            float* flow = fb[cur];
+            if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
+            for (int it = 0; it < iterations; it++) {
+                if ((rc = nsof_launch_blur_solve(ctx, n_pairs, dM, wk, hk, winsize, flow))) return rc;
+                if (it < iterations - 1)
+                    if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
+            }
         }
-        prev_flow = flow;
+        have_prev = true;
         pw = wk;
         ph = hk;
-        pp ^= 1;
     }
+    if (fb[cur] != d_flow)  // cannot happen by construction; keep the result correct regardless
+        NSOF_HIP(ctx, hipMemcpyAsync(d_flow, fb[cur], B * n0 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return NSOF_OK;
 }
 

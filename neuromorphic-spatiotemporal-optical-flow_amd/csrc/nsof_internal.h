@@ -79,3 +79,7 @@ int nsof_launch_update_matrices(nsof_ctx* ctx, int n_pairs, const float* R0, con
 int nsof_launch_blur_solve(nsof_ctx* ctx, int n_pairs, const float* M, int W, int H, int winsize, float* flow);
 int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw,
                               int dh, float mul);
+bool nsof_iterate_supported(int winsize, int W, int H);
+// Fused iteration; flow_in != flow_out.
+int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                        const float* flow_in, float* flow_out, int W, int H, int winsize);

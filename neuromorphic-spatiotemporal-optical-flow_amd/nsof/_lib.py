@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnsof.so")
 
 NSOF_OK, NSOF_EINVAL, NSOF_ESHAPE, NSOF_EDEVICE, NSOF_ENOMEM, NSOF_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_COUNT = range(7)
+K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_COUNT = range(8)
 
 _vp, _i, _d, _f, _sz, _pd, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t, C.c_ssize_t, C.c_int64
 
@@ -31,6 +31,7 @@ SIGNATURES = {
     "nsof_stage_polyexp": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _vp]),
     "nsof_stage_update_matrices": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "nsof_stage_blur_solve": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "nsof_stage_iterate": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "nsof_stage_flow_upsample": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _d]),
     "nsof_prof_enable": (_i, [_vp, C.c_uint]),
     "nsof_prof_collect": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),

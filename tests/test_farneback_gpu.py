@@ -126,6 +126,30 @@ def test_blur_solve(ctx, oracle, torch_dev, winsize, shape):
     assert (got != want).mean() < 0.01
 
 
+@pytest.mark.parametrize("winsize", [15, 3, 4, 2, 9, 17])
+@pytest.mark.parametrize("shape", [(135, 240), (97, 531), (20, 40)])
+def test_fused_iteration(ctx, oracle, torch_dev, winsize, shape):
+    """k_iterate == update_matrices followed by blur+solve (the unfused oracle stages)."""
+    import torch
+    from nsof import synth
+    h, w = shape
+    prev, nxt = synth.make_pair(9, h, w)
+    R0, R1, flow = _level_state(oracle, prev, nxt, 5, 1.2, 6)
+    M = oracle.update_matrices(R0, R1, flow)
+    want, _ = oracle.update_flow_blur(R0, R1, flow, M, winsize, False)
+    Rp = np.stack([np.stack([_planar(R0), _planar(R1)])] * 2)
+    dR, dF = _dev(torch_dev, Rp), _dev(torch_dev, np.stack([flow, flow]))
+    out = torch.zeros((2, h, w, 2), dtype=torch.float32, device=torch_dev)
+    torch.cuda.synchronize()
+    ctx.check(ctx._lib.nsof_stage_iterate(ctx.ptr, 2, dR.data_ptr(), dF.data_ptr(), w, h, winsize, out.data_ptr()))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0], got[1])
+    d = np.abs(got[0] - want)
+    assert d.max() <= 1e-6 * max(1.0, np.abs(want).max()), d.max()
+    assert (got[0] != want).mean() < 0.01
+
+
 @pytest.mark.parametrize("pyr_scale,src,dst", [(0.5, (68, 120), (135, 240)), (0.6, (58, 79), (97, 131)),
                                                (0.5, (135, 240), (270, 480))])
 def test_flow_upsample_bit_exact(ctx, oracle, torch_dev, pyr_scale, src, dst):
