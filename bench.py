@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=64, help="frame pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--params", choices=["A", "B", "C"], default="A")
@@ -198,24 +198,21 @@ def main():
             out["roofline_polyexp"] = roof(_lib.K_POLYEXP)
             out["kernel_ms_per_step"] = {_lib.load().nsof_kernel_name(k).decode(): round(prof[k][0] / args.steps, 3)
                                          for k in kernel_ids}
-            tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch
+            tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived HBM bytes (see its _doc)
             if os.path.exists(tj):
                 with open(tj) as f:
-                    tr = json.load(f)
+                    tr = json.load(f).get("kernels", {})
                 for key in ("roofline", "roofline_polyexp"):
-                    ent = tr.get(cfg_key(args), {}).get(out[key]["kernel"]) if out.get(key) else None
+                    ent = tr.get(out[key]["kernel"]) if out.get(key) else None
                     if ent is not None:
-                        out[key]["traffic"] = ent
+                        out[key]["traffic"] = int(out[key]["algorithmic_bytes_per_launch"] *
+                                                  ent["traffic_over_algorithmic"])
         if world == 1 and args.cpu_sample > 0:
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
-
-
-def cfg_key(args):
-    return f"{args.width}x{args.height}_{args.params}_{args.pairs}"
 
 
 def cpu_leg(nsof, p, prevs, nexts, flow, k):

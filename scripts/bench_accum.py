@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Accumulator benchmark (BASELINE.json config 5): synthetic 3840x2160 event stream at 1 M events/s,
+1 ms slices, scheme 1, active_v=-6, silent_v=0.  Reports slices/s for
+  sparse : the default path (silent_v in the dead zone -> only event pixels are visited)
+  dense  : every pixel visited, up to 32 slices fused per pass (nsof_accum_set_dense) -- the HBM-roofline run
+and the CPU oracle (oracle/accum_ref.c, 1 thread) on a bounded number of slices.  One JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "neuromorphic-spatiotemporal-optical-flow_amd")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--events", type=int, default=1_000_000)
+    ap.add_argument("--duration-us", type=int, default=1_000_000)
+    ap.add_argument("--slice-us", type=int, default=1000)
+    ap.add_argument("--cpu-slices", type=int, default=40)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    import numpy as np
+    import nsof
+    from nsof import _lib
+    from nsof.accumulator import Accumulator, slice_index_array
+    rng = np.random.default_rng(5)
+    n, W, H = a.events, a.width, a.height
+    x = rng.integers(0, W, n)
+    y = rng.integers(0, H, n)
+    k = int(0.3 * n)                       # 30 % of the events in a drifting 400x300 window
+    t = np.sort(rng.integers(0, a.duration_us, n)).astype(np.int64)
+    drift = (t[:k] * 600e-6).astype(np.int64)
+    x[:k] = (rng.integers(0, 400, k) + drift) % W
+    y[:k] = rng.integers(0, 300, k) + H // 3
+    p = rng.integers(0, 2, n)
+    x, y, p = x.astype(np.int16), y.astype(np.int16), p.astype(np.int8)
+    idx = slice_index_array(t, a.slice_us)
+    nsl = len(idx) - 1
+    ctx = nsof.Context(0)
+    out = {"workload": f"{W}x{H} sensor, {n} events over {a.duration_us} us, {a.slice_us} us slices ({nsl} slices), "
+                       f"scheme 1, active_v=-6, silent_v=0", "slices": nsl}
+    finals = {}
+    for mode in ("sparse", "dense"):
+        acc = Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=ctx, dense=(mode == "dense"))
+        acc.step(x, y, p, t, idx, snap_every=0)   # warm-up (allocations, event staging)
+        ctx.synchronize()
+        best = 1e9
+        for _ in range(a.reps):
+            acc.reset()
+            ctx.synchronize()
+            ctx.prof_enable(_lib.K_ACCUM)
+            t0 = time.perf_counter()
+            acc.step(x, y, p, t, idx, snap_every=0)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            kms, kn = ctx.prof_collect(_lib.K_ACCUM)
+            ctx.prof_enable()
+            best = min(best, dt)
+        finals[mode] = acc.w(0)
+        acc.close()
+        ent = {"slices_per_s": round(nsl / best, 1), "wall_ms": round(best * 1e3, 2), "kernel_ms": round(kms, 3),
+               "kernel_launches": kn}
+        if mode == "dense":
+            # fused pass: w read+written (8 B/px) + mask read (4 B/px, + rare clears) per group of <= 32 slices
+            groups = (nsl + 31) // 32
+            alg = groups * W * H * 12 + n * 5
+            ent.update(algorithmic_bytes=alg, achieved_gbs=round(alg / (kms * 1e-3) / 1e9, 1),
+                       frac_of_8tbs=round(alg / (kms * 1e-3) / 8e12, 4),
+                       per_slice_equivalent_gbs=round(nsl * W * H * 8 / (kms * 1e-3) / 1e9, 1))
+        out[mode] = ent
+    out["dense_equals_sparse"] = bool(np.array_equal(finals["sparse"], finals["dense"]))
+    # CPU oracle on a bounded prefix
+    from oracle import oracle as O
+    O.build()
+    cs = min(a.cpu_slices, nsl)
+    hi = idx[cs]
+    tt = t[:hi].copy()
+    t0 = time.perf_counter()
+    ref = O.accum_simulate(x[:hi], y[:hi], p[:hi], tt, H, W, 1, "split", a.slice_us, -6.0, 0.0)
+    dt = time.perf_counter() - t0
+    nref = len(O.accum_slice_bounds(tt, a.slice_us)) - 1
+    out["cpu_baseline"] = {"value": round(nref / dt, 2), "unit": "slices/s", "cores": 1, "kind": "port",
+                           "sample": f"first {nref} slices, oracle/accum_ref.c incl. its per-slice resistance snapshots"}
+    acc = Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=ctx)
+    acc.step(x, y, p, t, idx[:nref + 1], snap_every=0)
+    out["max_abs_w_vs_oracle"] = float(np.abs(acc.w(0) - ref["w_final"]).max())
+    acc.close()
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
