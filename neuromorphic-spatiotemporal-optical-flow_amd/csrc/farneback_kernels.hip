@@ -8,6 +8,8 @@
 //
 // All kernels are HBM/L2-bound stencils: no MFMA.  Layouts: images [n][h][w] f32,
 // R and M planar [n][5][h][w] f32 (coalesced 256 B per wave per plane), flow [n][h][w][2].
+#include <cstdlib>
+
 #include "nsof_internal.h"
 
 namespace {
@@ -332,6 +334,91 @@ __global__ __launch_bounds__(256) void k_prep_direct(const uint8_t* __restrict__
         }
     }
     // rows of H0/H1 are r0-R .. r0-R+KS; the window of r1 = r0+1 starts one entry later
+    const float B00 = col_filter<KS>(tk, KS, R, [&](int q) { return H0[q]; });
+    const float B01 = col_filter<KS>(tk, KS, R, [&](int q) { return H1[q]; });
+    float B10 = B00, B11 = B01;
+    if (r1 != r0) {
+        B10 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H0[q]; });
+        B11 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H1[q]; });
+    }
+    const float t0 = B00 * a0 + B01 * a1;
+    const float t1 = B10 * a0 + B11 * a1;
+    out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+}
+
+// Resampled level, two passes (kernel sizes 9 and 19: levels 2 and 3 of the reference's parameter sets).
+// The destination samples only 2 source columns per destination column and 2 source rows per destination row,
+// so the separable blur is evaluated only there:
+//   pass A  k_prep_rows  thread <-> (source row, sampled column): KS-tap row filter -> HA [n][H][2*wk] f32
+//   pass B  k_prep_cols  thread <-> destination pixel: KS-tap column filter at its 2 rows x 2 columns of HA
+//                        (reflected rows), then the bilinear blend (horizontal first, as resize does).
+// Both are plain thread-per-output kernels (no LDS, no barriers, full occupancy); HA is 2-4 MB per frame and
+// is re-read from L2/MALL.  Same operation order as the tiled/direct kernels (bit-identical results).
+constexpr int PREPA_ROWS = 8;
+template <int KS>
+__global__ __launch_bounds__(256) void k_prep_rows(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                    ptrdiff_t img_stride, int W, int H, int wk, double scale_x,
+                                                    nsof_blur_taps t, float* __restrict__ HA)
+{
+    constexpr int R = KS / 2, ND = (KS + 3) / 4;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rbase = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PREPA_ROWS;
+    if (j >= 2 * wk || rbase >= H) return;
+    int sx;
+    float a;
+    lin_coord_x(j >> 1, scale_x, W, sx, a);
+    const int c = (j & 1) ? min(sx + 1, W - 1) : sx;
+    const bool fast = c - R >= 0 && c - R + 4 * ND <= W;
+    auto tk = [&](int q) { return t.k[q]; };
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    float* dst = HA + ((size_t)blockIdx.z * H) * (2 * wk) + j;
+#pragma unroll 2
+    for (int q = 0; q < PREPA_ROWS; q++) {
+        const int r = rbase + q;
+        if (r >= H) break;
+        const uint8_t* rowp = img + (ptrdiff_t)r * row_stride;
+        float b[KS];
+        if (fast) {
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                unsigned v;
+                __builtin_memcpy(&v, rowp + (c - R) + 4 * d, 4);   // unaligned dword load
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (4 * d + e < KS) b[4 * d + e] = (float)((v >> (8 * e)) & 0xffu);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KS; i++) b[i] = (float)rowp[reflect101(c - R + i, W)];
+        }
+        dst[(size_t)r * (2 * wk)] = row_filter<KS>(tk, KS, R, [&](int i) { return b[i]; });
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_prep_cols(const float* __restrict__ HA, int W, int H, int wk, int hk,
+                                                    double scale_x, double scale_y, nsof_blur_taps t,
+                                                    float* __restrict__ out)
+{
+    constexpr int R = KS / 2;
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= wk || dy >= hk) return;
+    int sx, sy;
+    float a1, b1;
+    lin_coord_x(dx, scale_x, W, sx, a1);
+    lin_coord_y(dy, scale_y, sy, b1);
+    const float a0 = 1.f - a1, b0 = 1.f - b1;
+    const int r0 = clampi(sy, 0, H - 1), r1 = clampi(sy + 1, 0, H - 1);
+    auto tk = [&](int q) { return t.k[q]; };
+    const float2* Hz = reinterpret_cast<const float2*>(HA) + ((size_t)blockIdx.z * H) * wk + dx;
+    float H0[KS + 1], H1[KS + 1];
+#pragma unroll
+    for (int i = 0; i <= KS; i++) {
+        const float2 h = Hz[(size_t)reflect101(r0 - R + i, H) * wk];
+        H0[i] = h.x;
+        H1[i] = h.y;
+    }
     const float B00 = col_filter<KS>(tk, KS, R, [&](int q) { return H0[q]; });
     const float B01 = col_filter<KS>(tk, KS, R, [&](int q) { return H1[q]; });
     float B10 = B00, B11 = B01;
@@ -757,6 +844,17 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
             if (taps.ksize == 3) NSOF_PREP_DIRECT(3);
             else NSOF_PREP_DIRECT(5);
 #undef NSOF_PREP_DIRECT
+        } else if (taps.ksize == 19 && scale_x >= 1.0 && scale_y >= 1.0 && getenv("NSOF_PREP_TILED") == nullptr) {
+            // measured at 1080p x 64 frames: 19 taps 459 -> 244 us; 9 taps is still faster tiled (231 vs 254 us)
+            int rc = nsof_ws_reserve(ctx, &ctx->tmp, &ctx->tmp_bytes, (size_t)n_img * H * 2 * wk * sizeof(float));
+            if (rc) return rc;
+            float* HA = static_cast<float*>(ctx->tmp);
+            dim3 ga((2 * wk + 63) / 64, (H + 4 * PREPA_ROWS - 1) / (4 * PREPA_ROWS), n_img);
+            dim3 gb((wk + 63) / 64, (hk + 3) / 4, n_img);
+            hipLaunchKernelGGL(k_prep_rows<19>, ga, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk,
+                               scale_x, taps, HA);
+            hipLaunchKernelGGL(k_prep_cols<19>, gb, dim3(256), 0, ctx->stream, HA, W, H, wk, hk, scale_x, scale_y, taps,
+                               out);
         } else if (smem <= 60 * 1024 && scale_x >= 1.0 && scale_y >= 1.0) {
             dim3 grid((wk + PREP_TW - 1) / PREP_TW, (hk + PREP_TH - 1) / PREP_TH, n_img);
 #define NSOF_PREP_TILED(KS)                                                                                        \

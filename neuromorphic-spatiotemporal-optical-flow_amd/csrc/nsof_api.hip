@@ -137,6 +137,7 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     }
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->stage) hipFree(ctx->stage);
+    if (ctx->tmp) hipFree(ctx->tmp);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

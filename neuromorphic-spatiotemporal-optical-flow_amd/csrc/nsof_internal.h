@@ -31,6 +31,9 @@ struct nsof_ctx {
     // staging for the host-pointer entry point
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // row-filtered intermediate of the two-pass pyramid kernels
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
 };
 
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
