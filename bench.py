@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="frame pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--params", choices=["A", "B", "C"], default="A")
@@ -120,9 +120,11 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torch.distributed.run: always RCCL
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)
 
     p = {"A": PARAMS_A, "B": PARAMS_B, "C": PARAMS_C}[args.params]
@@ -137,7 +139,7 @@ def main():
         nsof.farneback_batch(prevs, nexts, flow, n, h, w, p, ctx=ctx)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -154,7 +156,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -210,7 +212,8 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 

@@ -273,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void k_iterate(const float* __restrict__ R0
 // The plain walker above is limited by registers (the M ring and the loads in flight compete for one
 // thread's budget) and by code size (static ring slots force unrolling a whole ring period).  Here:
 //   waves 0-3   consumers  thread <-> column: the 5 double column sums in registers; row sums + solve
-//   waves 4-7   producers A, waves 8-11 producers B: stateless; thread <-> column computes M for the two rows
-//               of every other step and keeps the R0/R1 loads of its next TWO steps in flight
-//               -> 8 rows of loads in flight per column.
+//   waves 4-7   producers A, waves 8-11 producers B: stateless; thread <-> column computes M for row A resp.
+//               B of every 2-row step and keeps the R0/R1 loads of its next FOUR steps in flight
+//               -> 8 rows of loads in flight per column, and both groups work in every window.
 // M rows go from producers to consumers through a ring in LDS (2m+6 rows x 5 planes x 256 columns,
 // 100 KB for winsize 15) that also serves as the window history (M[y-m-1] is read back from it), indexed
 // dynamically -- no unrolling.  ONE block barrier per 2-row step (the column sums are double-buffered), and the
@@ -290,25 +290,26 @@ struct PCGeom {
     static constexpr size_t SMEM = sizeof(double) * 4 * 5 * COLS + sizeof(float) * RL * 5 * COLS;
 };
 
-// Producer group G produces step t (rows 2t+m, 2t+m+1 of the stream) from the loads in in[J].
-template <int MH, int COLS, int J>
-__device__ __forceinline__ void produce_step(RowIn (&in)[2][2], float2 (&fl)[2], float (*mring)[5][COLS],
-                                             const Planes& R0, const Planes& R1, const char* FinB, int W, int H,
-                                             int xc, int col, int t)
+// Producer group G owns row G of every 2-row step: stream index i(t) = 2t + m + G.  It produces M for step t
+// from the loads in slot J = t & 3, then refills that slot with step t+4 (4 rows = 4 steps of loads in flight
+// per thread).  The gather addresses depend on the flow, so the flow of step t+4 was itself fetched four
+// windows earlier (fl[J]); a one-window flow lookahead makes every window wait for a full memory latency.
+template <int MH, int COLS, int G, int J>
+__device__ __forceinline__ void produce_row(RowIn (&in)[4], float2 (&fl)[4], float (*mring)[5][COLS], const Planes& R0,
+                                            const Planes& R1, const char* FinB, int W, int H, int xc, int col, int t)
 {
     constexpr int RL = PCGeom<MH, COLS>::RL;
+    const int i = 2 * t + MH + G;
+#if defined(NSOF_ABL) && (NSOF_ABL == 4 || NSOF_ABL == 5)   // timing-only build: idle producers
+    return;
+#endif
+    float Mn[5];
+    matrix_from(in[J], xc, min(i, H - 1), W, H, Mn);
+    const int slot = (i + MH + 1) % RL;      // stream index -MH-1 (first replicated row) lives in slot 0
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int i = 2 * t + MH + q;
-        float Mn[5];
-        matrix_from(in[J][q], xc, min(i, H - 1), W, H, Mn);
-        const int slot = (i + MH + 1) % RL;      // stream index -MH-1 (first replicated row) lives in slot 0
-#pragma unroll
-        for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
-        // refill: my step after next is t + 4; its flow was fetched when I produced t - 2
-        issue_row(in[J][q], R0, R1, W, H, xc, min(i + 8, H - 1), fl[q]);
-        fl[q] = *reinterpret_cast<const float2*>(FinB + ((unsigned)min(i + 12, H - 1) * (unsigned)W + (unsigned)xc) * 8u);
-    }
+    for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
+    issue_row(in[J], R0, R1, W, H, xc, min(i + 8, H - 1), fl[J]);
+    fl[J] = *reinterpret_cast<const float2*>(FinB + ((unsigned)min(i + 16, H - 1) * (unsigned)W + (unsigned)xc) * 8u);
 }
 
 // Producer waves of group G: their own loop, with exactly the same barrier sequence as the consumers.
@@ -316,40 +317,36 @@ template <int MH, int COLS, int G>
 __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Planes& R0, const Planes& R1,
                                               const char* FinB, int W, int H, int xc, int col, int nsteps)
 {
-    RowIn in[2][2];
-    float2 fl[2];
+    RowIn in[4];
+    float2 fl[4];
     auto flowAt = [&](int r) {
         return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
     };
-    // my steps are G, G+2, G+4, ...; two of them in flight
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < 4; j++) {   // steps 0..3 in flight
+        const int r = min(2 * j + MH + G, H - 1);
+        issue_row(in[j], R0, R1, W, H, xc, r, flowAt(r));
+    }
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int r = min(2 * (G + 2 * j) + MH + q, H - 1);
-            issue_row(in[j][q], R0, R1, W, H, xc, r, flowAt(r));
-        }
-#pragma unroll
-    for (int q = 0; q < 2; q++) fl[q] = flowAt(min(2 * (G + 4) + MH + q, H - 1));
+    for (int j = 0; j < 4; j++) fl[j] = flowAt(min(2 * (j + 4) + MH + G, H - 1));   // flows of steps 4..7
     // Barrier sequence (identical in all roles): B_init, then B(s) for s = 0..nsteps-1.
-    //   before B_init            group 0 produces step 0
-    //   between B_init and B(0)  group 1 produces step 1            (consumers: column sums of step 0)
-    //   between B(s) and B(s+1)  group s&1 produces step s+2        (consumers: row sums + solve of step s,
+    //   before B_init            step 0 is produced
+    //   between B_init and B(0)  step 1                              (consumers: column sums of step 0)
+    //   between B(s) and B(s+1)  step s+2                            (consumers: row sums + solve of step s,
     //                                                                 column sums of step s+1)
-    // In the 4-step period starting at sb: s=sb -> G0 slot 1, sb+1 -> G1 slot 1, sb+2 -> G0 slot 0, sb+3 -> G1 slot 0.
-    if (G == 0) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 0);
+    produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 0);
     __syncthreads();
-    if (G == 1) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 1);
+    produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 1);
     for (int sb = 0; sb < nsteps; sb += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int s = sb + u;
             if (s >= nsteps) break;
             __syncthreads();
-            if (G == 0 && u == 0) produce_step<MH, COLS, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
-            if (G == 1 && u == 1) produce_step<MH, COLS, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
-            if (G == 0 && u == 2) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
-            if (G == 1 && u == 3) produce_step<MH, COLS, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (u == 0) produce_row<MH, COLS, G, 2>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (u == 1) produce_row<MH, COLS, G, 3>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (u == 2) produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (u == 3) produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
         }
     }
 }
@@ -396,6 +393,9 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
     int slot_new = (2 * MH + 1) % RL;           // stream index m   -> slot 2m+1
     int slot_old = 0;                           // stream index -m-1 -> slot 0
     auto column_sums = [&](int buf) {           // two more rows enter the window of this thread's column
+#if defined(NSOF_ABL) && (NSOF_ABL == 4 || NSOF_ABL == 6)   // timing-only build: idle consumers
+        return;
+#endif
 #pragma unroll
         for (int q = 0; q < 2; q++) {
 #pragma unroll
@@ -413,7 +413,9 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
         __syncthreads();   // B(s): column sums of step s visible; rows of step s+1 are in the ring
         const int buf = s & 1;
         const int yo = 2 * s + hrow, xo = x0 + 2 * t;
-#if defined(NSOF_ABL) && NSOF_ABL == 2   // timing-only build: no row sums / solve
+#if defined(NSOF_ABL) && (NSOF_ABL == 4 || NSOF_ABL == 6)
+        (void)xo; (void)yo;
+#elif defined(NSOF_ABL) && NSOF_ABL == 2   // timing-only build: no row sums / solve
         if (2 * t < SW && yo < H && xo < W) {
             float2* dst = Fout + (size_t)yo * W + xo;
             dst[0] = make_float2((float)sv[2 * buf + hrow][0][2 * t], (float)sv[2 * buf + hrow][1][2 * t]);
