@@ -19,5 +19,8 @@ from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_lev
 from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, load_events, resistance_exp,  # noqa: F401
                           simulate, slice_indices, update_state)
 
+from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, gating_maps,  # noqa: F401,E402
+                     opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
+
 __all__ = ["calcOpticalFlowFarneback", "install", "uninstall", "FarnebackParams", "farneback_batch", "Context",
            "default_context", "simulate", "update_state", "resistance_exp", "Accumulator", "NsofError", "error"]

@@ -1,0 +1,202 @@
+"""ROI gating + flow dispatch: host-side mirror of the reference's ``opticalFlow3D`` family
+(/root/reference/optical_flow_seg.py:115-252, 426-435; duplicated verbatim in optical_flow_ob.py,
+optical_flow_prediction.py, optical_flow_yolo.py).  SURVEY.md section 8f row 1.
+
+The gating maps are tiny (4x4 .. 24x13): thresholding, 4-connected components and bounding boxes stay on
+the host; the flow of every ROI crop runs on the GPU through ``calcOpticalFlowFarneback`` (strided views are
+passed straight to the C ABI).  Same names, argument order and return tuples as the reference; the module-level
+constants of the reference scripts (MEMSIZE, THRES, EXTEND_*, FLAG) become a ``GatingConfig``.
+"""
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .farneback import PARAMS_A, PARAMS_B, PARAMS_C, FarnebackParams, calcOpticalFlowFarneback
+
+# cv2.CC_STAT_* column indices of the stats array
+CC_STAT_LEFT, CC_STAT_TOP, CC_STAT_WIDTH, CC_STAT_HEIGHT, CC_STAT_AREA = 0, 1, 2, 3, 4
+
+
+@dataclass
+class GatingConfig:
+    """Per-dataset constants (data/*/Parameters.txt; optical_flow_seg.py:36-49,73-81)."""
+    MEMSIZE: int = 80
+    OFFSET: int = 0
+    EXTEND_HEIGHT_UPPER: int = 20
+    EXTEND_HEIGHT_LOWER: int = 20
+    EXTEND_WIDTH_LEFT: int = 20
+    EXTEND_WIDTH_RIGHT: int = 20
+    THRES: int = 250
+    CONNECT: int = 4
+    FLAG: int = 2                     # 1 = one flow call per component, 2 = one call on the union box
+    farneback_params: FarnebackParams = PARAMS_A
+    bug_compatible: bool = True       # the scripts gate on slice OFFSET+i (memimg2 := memimg1, seg.py:435)
+    # timing lists the reference keeps at module level (optical_flow_seg.py:51-59)
+    mem_opticalflow_times: list = field(default_factory=list)
+    mem_cal_times: list = field(default_factory=list)
+    mem_velocity_times: list = field(default_factory=list)
+
+
+DATASETS = {
+    "grasp": dict(MEMSIZE=80, OFFSET=0, EXTEND_HEIGHT_UPPER=20, EXTEND_HEIGHT_LOWER=20, EXTEND_WIDTH_LEFT=20,
+                  EXTEND_WIDTH_RIGHT=20, THRES=250, FLAG=2, farneback_params=PARAMS_A),
+    "autodriving": dict(MEMSIZE=200, OFFSET=15, EXTEND_HEIGHT_UPPER=60, EXTEND_HEIGHT_LOWER=60, EXTEND_WIDTH_LEFT=60,
+                        EXTEND_WIDTH_RIGHT=60, THRES=114, FLAG=1, farneback_params=PARAMS_B),
+    "uav": dict(MEMSIZE=40, OFFSET=15, EXTEND_HEIGHT_UPPER=30, EXTEND_HEIGHT_LOWER=30, EXTEND_WIDTH_LEFT=30,
+                EXTEND_WIDTH_RIGHT=30, THRES=114, FLAG=1, farneback_params=PARAMS_B),
+    "uavnew2": dict(MEMSIZE=40, OFFSET=0, EXTEND_HEIGHT_UPPER=60, EXTEND_HEIGHT_LOWER=60, EXTEND_WIDTH_LEFT=60,
+                    EXTEND_WIDTH_RIGHT=60, THRES=245, FLAG=1, farneback_params=PARAMS_A),
+    "tabletennis": dict(MEMSIZE=10, OFFSET=0, EXTEND_HEIGHT_UPPER=20, EXTEND_HEIGHT_LOWER=20, EXTEND_WIDTH_LEFT=20,
+                        EXTEND_WIDTH_RIGHT=20, THRES=245, FLAG=2, farneback_params=PARAMS_C),
+}
+
+
+def dataset_config(name, **overrides):
+    kw = dict(DATASETS[name])
+    kw.update(overrides)
+    return GatingConfig(**kw)
+
+
+def current_to_gray(mem_state):
+    """Device current (A) -> 8-bit gating map: ``uint8(clip(-3366/log10(I) - 306, 0, 255))``
+    (optical_flow_seg.py:426-431)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = -3366 / np.log10(np.asarray(mem_state, np.double)) - 306
+    return np.clip(g, 0, 255).astype(np.uint8)
+
+
+def gating_maps(mem_state, i, cfg):
+    """(memimg1, memimg2) for frame pair i from the ``constructed3DMatrix`` stack (seg.py:416-437).
+    With ``cfg.bug_compatible`` memimg2 is a copy of memimg1, as in the shipped scripts."""
+    m1 = current_to_gray(mem_state[:, :, cfg.OFFSET + i])
+    m2 = m1.astype(np.uint8) if cfg.bug_compatible else current_to_gray(mem_state[:, :, cfg.OFFSET + i + 1])
+    return m1, m2
+
+
+def update_transition_pic(prev_memristor, transition_pic, thres):
+    """optical_flow_seg.py:115-121 (the reference jit-compiles this double loop with numba)."""
+    h = min(prev_memristor.shape[0], transition_pic.shape[0])
+    w = min(prev_memristor.shape[1], transition_pic.shape[1])
+    if prev_memristor.shape[0] > transition_pic.shape[0] or prev_memristor.shape[1] > transition_pic.shape[1]:
+        raise IndexError("gating map larger than the transition picture (the reference would write out of bounds)")
+    transition_pic[:h, :w][prev_memristor[:h, :w] >= thres] = 255
+    return transition_pic
+
+
+def connectedComponentsWithStats(image, connectivity=4):  # noqa: N802
+    """Subset of ``cv2.connectedComponentsWithStats`` used by the reference (seg.py:223): labels in raster order of
+    each component's first pixel, label 0 = background, stats columns LEFT, TOP, WIDTH, HEIGHT, AREA."""
+    img = np.asarray(image) != 0
+    h, w = img.shape
+    labels = np.zeros((h, w), np.int32)
+    nbrs = [(-1, 0), (1, 0), (0, -1), (0, 1)]
+    if connectivity == 8:
+        nbrs += [(-1, -1), (-1, 1), (1, -1), (1, 1)]
+    elif connectivity != 4:
+        raise ValueError("connectivity must be 4 or 8")
+    n = 0
+    for y in range(h):
+        for x in range(w):
+            if img[y, x] and labels[y, x] == 0:
+                n += 1
+                labels[y, x] = n
+                stack = [(y, x)]
+                while stack:
+                    cy, cx = stack.pop()
+                    for dy, dx in nbrs:
+                        ny, nx = cy + dy, cx + dx
+                        if 0 <= ny < h and 0 <= nx < w and img[ny, nx] and labels[ny, nx] == 0:
+                            labels[ny, nx] = n
+                            stack.append((ny, nx))
+    stats = np.zeros((n + 1, 5), np.int32)
+    cents = np.zeros((n + 1, 2), np.float64)
+    for lab in range(n + 1):
+        ys, xs = np.nonzero(labels == lab)
+        if ys.size == 0:
+            continue
+        stats[lab] = (xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1, ys.size)
+        cents[lab] = (xs.mean(), ys.mean())
+    return n + 1, labels, stats, cents
+
+
+def _roi(x, y, a, b, w, h, pixel_width, pixel_height, cfg):
+    x_start = max(x * pixel_width - cfg.EXTEND_WIDTH_LEFT, 0)
+    y_start = max(y * pixel_height - cfg.EXTEND_HEIGHT_UPPER, 0)
+    x_end = min((x + a) * pixel_width + cfg.EXTEND_WIDTH_RIGHT, w)
+    y_end = min((y + b) * pixel_height + cfg.EXTEND_HEIGHT_LOWER, h)
+    return int(x_start), int(y_start), int(x_end), int(y_end)
+
+
+def process_separate_regions(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_height, cfg, flow_fn):
+    """FLAG == 1 (optical_flow_seg.py:123-166): one flow call per connected component."""
+    region_list, regions_info = [], []
+    h, w = rgbimg1.shape[:2]
+    for i in range(1, len(stats)):
+        t0 = time.time()
+        x, y, a, b = (int(stats[i, k]) for k in (CC_STAT_LEFT, CC_STAT_TOP, CC_STAT_WIDTH, CC_STAT_HEIGHT))
+        x_start, y_start, x_end, y_end = _roi(x, y, a, b, w, h, pixel_width, pixel_height, cfg)
+        regions_info.append((x_start, y_start, x_end, y_end))
+        prev_region = rgbimg1[y_start:y_end, x_start:x_end]
+        next_region = rgbimg2[y_start:y_end, x_start:x_end]
+        cfg.mem_cal_times.append(time.time() - t0)
+        region_list.append(prev_region.shape[0] * prev_region.shape[1] / (h * w) * 100)
+        if prev_region.size > 0 and next_region.size > 0:
+            t0 = time.time()
+            flow[y_start:y_end, x_start:x_end] = flow_fn(prev_region, next_region, None,
+                                                         **cfg.farneback_params.as_kwargs())
+            cfg.mem_velocity_times.append(time.time() - t0)
+        else:
+            cfg.mem_velocity_times.append(0)
+    return flow, cfg.mem_cal_times, cfg.mem_velocity_times, region_list, len(stats), regions_info
+
+
+def process_merged_region(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_height, cfg, flow_fn):
+    """FLAG == 2 (optical_flow_seg.py:168-209): one flow call on the union bounding box."""
+    region_list = []
+    h, w = rgbimg1.shape[:2]
+    t0 = time.time()
+    idx = range(1, len(stats))
+    x_min = min(int(stats[i, CC_STAT_LEFT]) for i in idx)
+    y_min = min(int(stats[i, CC_STAT_TOP]) for i in idx)
+    x_max = max(int(stats[i, CC_STAT_LEFT] + stats[i, CC_STAT_WIDTH]) for i in idx)
+    y_max = max(int(stats[i, CC_STAT_TOP] + stats[i, CC_STAT_HEIGHT]) for i in idx)
+    x_start, y_start, x_end, y_end = _roi(x_min, y_min, x_max - x_min, y_max - y_min, w, h, pixel_width,
+                                          pixel_height, cfg)
+    prev_region = rgbimg1[y_start:y_end, x_start:x_end]
+    next_region = rgbimg2[y_start:y_end, x_start:x_end]
+    cfg.mem_cal_times.append(time.time() - t0)
+    region_list.append(prev_region.shape[0] * prev_region.shape[1] / (h * w) * 100)
+    if prev_region.size > 0 and next_region.size > 0:
+        t0 = time.time()
+        flow[y_start:y_end, x_start:x_end] = flow_fn(prev_region, next_region, None,
+                                                     **cfg.farneback_params.as_kwargs())
+        cfg.mem_velocity_times.append(time.time() - t0)
+    return flow, cfg.mem_cal_times, cfg.mem_velocity_times, region_list, (x_start, y_start, x_end, y_end)
+
+
+def opticalFlow3D(memimg1, memimg2, rgbimg1, rgbimg2, pixel_width, pixel_height, cfg=None,  # noqa: N802
+                  flow_fn=calcOpticalFlowFarneback):
+    """optical_flow_seg.py:211-252.  Returns ``(flow float64 HxWx2, cal_times, vel_times, region_list,
+    num_labels, regions_info)`` for FLAG 1 and ``(flow, cal_times, vel_times, region_list, (x0, y0, x1, y1))`` for
+    FLAG 2 -- the caller negates the flow (seg.py:461)."""
+    cfg = cfg or GatingConfig()
+    t0 = time.time()
+    h, w = rgbimg1.shape[:2]
+    flow = np.zeros((h, w, 2))
+    transition_pic = np.zeros((int(h / pixel_height), int(w / pixel_width)))
+    transition_pic = update_transition_pic(memimg2, transition_pic, cfg.THRES).astype(np.uint8)
+    num_labels, _, stats, _ = connectedComponentsWithStats(transition_pic, connectivity=cfg.CONNECT)
+    if num_labels == 1:
+        dt = time.time() - t0
+        cfg.mem_cal_times.append(dt)
+        cfg.mem_opticalflow_times.append(dt)
+        if cfg.FLAG == 1:
+            return flow, cfg.mem_cal_times, cfg.mem_opticalflow_times, [], num_labels, []
+        return flow, cfg.mem_cal_times, cfg.mem_opticalflow_times, [], (0, 0, 0, 0)
+    if cfg.FLAG == 1:
+        out = process_separate_regions(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_height, cfg, flow_fn)
+    else:
+        out = process_merged_region(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_height, cfg, flow_fn)
+    cfg.mem_opticalflow_times.append(time.time() - t0)
+    return out

@@ -1,0 +1,129 @@
+"""ROI gating harness: host logic on CPU with the reference's own gating data
+(tests/golden/gating_maps.json = slices of data/*/constructed_3D_matrix.mat), flow calls on the GPU."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+# union boxes (x0, y0, x1, y1) of the first frame pairs, as recorded independently in SURVEY.md section 8f
+SURVEY_MERGED = {("grasp", 0): (460, 0, 1060, 1920), ("grasp", 1): (300, 0, 1060, 1140),
+                 ("grasp", 2): (540, 940, 1060, 1140), ("uavnew2", 0): (0, 60, 600, 600),
+                 ("uavnew2", 1): (180, 100, 420, 340), ("tabletennis", 0): (0, 0, 160, 160),
+                 ("tabletennis", 1): (70, 10, 160, 160)}
+
+
+@pytest.fixture(scope="module")
+def maps():
+    with open(golden_path("gating_maps.json")) as f:
+        d = json.load(f)
+    return {name: (tuple(ent["frame_hw"]),
+                   {int(k): np.array([[float(v) for v in row] for row in rows]) for k, rows in ent["slices"].items()})
+            for name, ent in d.items()}
+
+
+def test_current_to_gray(nsof_lib):
+    g = nsof_lib.current_to_gray(np.array([[1e-6, 4.752e-7, 3.8e-6, 6e-11, 0.0, 1.0]]))
+    # -3366/log10(1e-6) - 306 = 255 exactly; 1/Roff maps to ~226; anything >= 1 uA saturates; tiny currents -> 0
+    assert g.dtype == np.uint8 and g[0, 0] == 255 and g[0, 2] == 255 and g[0, 3] == 23 and g[0, 1] == 226
+    assert g[0, 4] == 0  # log10(0) = -inf -> -306 -> clipped to 0 (the reference silences the warning the same way)
+
+
+def test_connected_components_match_scipy(nsof_lib):
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    for shape in [(4, 4), (24, 13), (15, 15), (16, 16), (7, 31)]:
+        for p in (0.2, 0.5, 0.8):
+            img = (rng.random(shape) < p).astype(np.uint8) * 255
+            n, labels, stats, cents = nsof_lib.connectedComponentsWithStats(img, connectivity=4)
+            ref, nref = ndimage.label(img, structure=[[0, 1, 0], [1, 1, 1], [0, 1, 0]])
+            assert n == nref + 1
+            # same partition (label numbering: raster order of the first pixel in both)
+            assert np.array_equal(labels, ref)
+            for lab in range(1, n):
+                ys, xs = np.nonzero(ref == lab)
+                assert tuple(stats[lab]) == (xs.min(), ys.min(), xs.max() - xs.min() + 1, ys.max() - ys.min() + 1,
+                                             ys.size)
+            n8, *_ = nsof_lib.connectedComponentsWithStats(img, connectivity=8)
+            assert n8 - 1 == ndimage.label(img, structure=np.ones((3, 3)))[1]
+
+
+def test_roi_rectangles_from_reference_data(nsof_lib, maps):
+    from nsof import gating
+    calls = []
+
+    def fake_flow(prev, nxt, flow, **kw):
+        calls.append((prev.shape, kw))
+        return np.full(prev.shape + (2,), 1.5, np.float32)
+
+    for (name, k), want in SURVEY_MERGED.items():
+        (h, w), slices = maps[name]
+        cfg = gating.dataset_config(name, FLAG=2)
+        g = gating.current_to_gray(slices[k])
+        img = np.zeros((h, w), np.uint8)
+        calls.clear()
+        flow, cal, vel, regions, rect = gating.opticalFlow3D(g, g, img, img, cfg.MEMSIZE, cfg.MEMSIZE, cfg, fake_flow)
+        assert rect == want, (name, k, rect)
+        x0, y0, x1, y1 = rect
+        assert flow.dtype == np.float64 and flow.shape == (h, w, 2)
+        assert np.all(flow[y0:y1, x0:x1] == 1.5) and flow.sum() == 1.5 * 2 * (y1 - y0) * (x1 - x0)
+        assert len(calls) == 1 and calls[0][0] == (y1 - y0, x1 - x0)
+        assert calls[0][1] == cfg.farneback_params.as_kwargs()
+        assert abs(regions[0] - (y1 - y0) * (x1 - x0) / (h * w) * 100) < 1e-9
+
+
+def test_separate_regions_and_empty_map(nsof_lib, maps):
+    from nsof import gating
+    (h, w), slices = maps["uavnew2"]
+    cfg = gating.dataset_config("uavnew2")   # FLAG 1
+    g = gating.current_to_gray(slices[2])
+    img = np.zeros((h, w), np.uint8)
+    seen = []
+    out = gating.opticalFlow3D(g, g, img, img, cfg.MEMSIZE, cfg.MEMSIZE, cfg,
+                               lambda p, n, f, **kw: (seen.append(p.shape), np.zeros(p.shape + (2,), np.float32))[1])
+    flow, cal, vel, regions, num_labels, info = out
+    assert num_labels == 4 and info == [(220, 100, 380, 260), (260, 140, 420, 300), (220, 180, 380, 340)]
+    assert seen == [(160, 160)] * 3 and len(regions) == 3
+    # no pixel above threshold -> zero flow, regions (0,0,0,0) / []
+    (h2, w2), sl2 = maps["autodriving"]
+    cfg2 = gating.dataset_config("autodriving")
+    g2 = gating.current_to_gray(sl2[16])
+    img2 = np.zeros((h2, w2), np.uint8)
+    flow2, _, _, regions2, n2, info2 = gating.opticalFlow3D(g2, g2, img2, img2, cfg2.MEMSIZE, cfg2.MEMSIZE, cfg2,
+                                                            lambda *a, **k: 1 / 0)
+    assert n2 == 1 and regions2 == [] and info2 == [] and not flow2.any()
+    cfg3 = gating.dataset_config("autodriving", FLAG=2)
+    out3 = gating.opticalFlow3D(g2, g2, img2, img2, cfg3.MEMSIZE, cfg3.MEMSIZE, cfg3, lambda *a, **k: 1 / 0)
+    assert out3[4] == (0, 0, 0, 0)
+
+
+def test_gating_maps_bug_compatibility(nsof_lib, maps):
+    from nsof import gating
+    (h, w), slices = maps["grasp"]
+    stack = np.stack([slices[0], slices[1], slices[2]], -1)
+    cfg = gating.dataset_config("grasp")
+    m1, m2 = gating.gating_maps(stack, 0, cfg)
+    assert np.array_equal(m1, m2)                                   # shipped scripts: memimg2 := memimg1
+    cfg.bug_compatible = False
+    m1, m2 = gating.gating_maps(stack, 0, cfg)
+    assert np.array_equal(m2, gating.current_to_gray(slices[1])) and not np.array_equal(m1, m2)
+
+
+@pytest.mark.gpu
+def test_roi_flow_equals_standalone_crop(nsof_lib, ctx, maps):
+    """End to end on the GPU: the flow pasted into the canvas is the flow of the cropped pair."""
+    from nsof import gating, synth
+    (h, w), slices = maps["uavnew2"]
+    prev, nxt = synth.make_pair(77, h, w)
+    cfg = gating.dataset_config("uavnew2", FLAG=2)
+    g = gating.current_to_gray(slices[1])
+    flow_fn = lambda p, n, f, **kw: nsof_lib.calcOpticalFlowFarneback(p, n, f, **kw, ctx=ctx)  # noqa: E731
+    flow, _, _, _, (x0, y0, x1, y1) = gating.opticalFlow3D(g, g, prev, nxt, cfg.MEMSIZE, cfg.MEMSIZE, cfg, flow_fn)
+    assert (x0, y0, x1, y1) == (180, 100, 420, 340)
+    crop = nsof_lib.calcOpticalFlowFarneback(prev[y0:y1, x0:x1].copy(), nxt[y0:y1, x0:x1].copy(), None,
+                                             **cfg.farneback_params.as_kwargs(), ctx=ctx)
+    assert np.array_equal(flow[y0:y1, x0:x1], crop.astype(np.float64))
+    outside = flow.copy()
+    outside[y0:y1, x0:x1] = 0
+    assert not outside.any()
