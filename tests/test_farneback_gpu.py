@@ -252,3 +252,30 @@ def test_error_behaviour(nsof_lib, ctx, frames):
     # levels are truncated for small images (min_size 32), tiny images still work
     small = nsof_lib.calcOpticalFlowFarneback(prev[:33, :40], nxt[:33, :40], None, *A, ctx=ctx)
     assert small.shape == (33, 40, 2) and np.isfinite(small).all()
+
+
+def test_pipeline_4k_vs_oracle(nsof_lib, ctx, oracle):
+    """BASELINE config 5 frame size: one 3840x2160 pair, params A (the oracle needs ~4 s)."""
+    from nsof import synth
+    prev, nxt = synth.make_pair(5, 2160, 3840, shift=(3.0, 1.5))
+    got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=ctx)
+    want = oracle.farneback(prev, nxt, *A)
+    assert np.abs(got - want).max() <= PIPE_TOL
+
+
+@pytest.mark.parametrize("shape", [(33, 40), (64, 64), (161, 161), (801, 801), (1080, 1920)])
+def test_context_reuse_across_shapes(nsof_lib, ctx, oracle, shape):
+    """One context serves calls of changing size (workspace grows and is reused), as the ROI dispatcher needs."""
+    from nsof import synth
+    prev, nxt = synth.make_pair(shape[0], *shape)
+    for params in (Cc, A):
+        got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
+        assert np.abs(got - oracle.farneback(prev, nxt, *params)).max() <= PIPE_TOL
+
+
+def test_large_window_takes_unfused_path(nsof_lib, ctx, oracle, frames):
+    """winsize > 17 is outside the fused iteration kernel: the unfused pair must give the same result class."""
+    prev, nxt = frames[(200, 303)]
+    p = (0.5, 2, 25, 2, 5, 1.2, 0)
+    got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *p, ctx=ctx)
+    assert np.abs(got - oracle.farneback(prev, nxt, *p)).max() <= PIPE_TOL
