@@ -98,6 +98,11 @@ int nsof_stage_blur_solve(nsof_ctx* ctx, int n_pairs, const float* d_M, int widt
  * d_flow_out must not alias.  winsize 2..17; larger windows take the unfused pair above. */
 int nsof_stage_iterate(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_flow_in, int width, int height,
                        int winsize, float* d_flow_out);
+/* The same with flow_in = resample(d_coarse_flow [src_h][src_w][2]) * (1/pyr_scale) formed on the fly (first
+ * iteration of a pyramid level): equals nsof_stage_flow_upsample followed by nsof_stage_iterate, bit for bit. */
+int nsof_stage_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_coarse_flow,
+                                int src_w, int src_h, int width, int height, int winsize, double pyr_scale,
+                                float* d_flow_out);
 int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* d_src, int src_w, int src_h,
                              float* d_dst, int dst_w, int dst_h, double pyr_scale);
 

@@ -282,6 +282,73 @@ __global__ __launch_bounds__(256, 2) void k_iterate(const float* __restrict__ R0
 // producers' gather for step s+2 overlaps the consumers' row sums + solve of step s.  Arithmetic and its order are identical
 // to k_iterate / the unfused kernels.
 // ---------------------------------------------------------------------------------------------
+// Where a thread's flow_in comes from.  UPS = false: the level's own flow buffer.  UPS = true (first iteration of
+// every level but the coarsest): the previous, coarser level's flow is resampled on the fly with exactly the
+// arithmetic of k_flow_upsample (resize INTER_LINEAR, then "flow *= 1/pyr_scale") -- the full-resolution initial
+// flow is then never written to or read from HBM.
+__device__ __forceinline__ void lin_x(int d, double scale, int slen, int& s, float& a)
+{
+    float f = (float)((d + 0.5) * scale - 0.5);
+    s = floor_f(f);
+    a = f - s;
+    if (s < 0) { s = 0; a = 0.f; }
+    if (s >= slen - 1) { s = slen - 1; a = 0.f; }
+}
+template <bool UPS>
+struct FlowSrc;
+// fetch() only issues loads (the result is consumed windows later); resolve() turns what was fetched into the flow.
+template <>
+struct FlowSrc<false> {
+    const char* base;   // flow_in of this pair
+    unsigned W, xc;
+    using Raw = float2;
+    __device__ __forceinline__ Raw fetch(int r) const
+    {
+        return *reinterpret_cast<const float2*>(base + ((unsigned)r * W + xc) * 8u);
+    }
+    __device__ __forceinline__ float2 resolve(const Raw& v) const { return v; }
+    __device__ __forceinline__ float2 at(int r) const { return fetch(r); }
+};
+template <>
+struct FlowSrc<true> {
+    const char* base;   // coarse flow of this pair, [sh][sw][2]
+    int sw, sh, sx, c1;
+    float a0, a1, mul;
+    double scale_y;
+    struct Raw {
+        float2 p00, p01, p10, p11;
+        float b1;
+    };
+    __device__ __forceinline__ Raw fetch(int r) const
+    {
+        Raw v;
+        float f = (float)((r + 0.5) * scale_y - 0.5);
+        const int sy = floor_f(f);
+        v.b1 = f - sy;
+        const unsigned r0 = (unsigned)clampi(sy, 0, sh - 1) * (unsigned)sw, r1 = (unsigned)clampi(sy + 1, 0, sh - 1) * (unsigned)sw;
+        v.p00 = *reinterpret_cast<const float2*>(base + (r0 + (unsigned)sx) * 8u);
+        v.p01 = *reinterpret_cast<const float2*>(base + (r0 + (unsigned)c1) * 8u);
+        v.p10 = *reinterpret_cast<const float2*>(base + (r1 + (unsigned)sx) * 8u);
+        v.p11 = *reinterpret_cast<const float2*>(base + (r1 + (unsigned)c1) * 8u);
+        return v;
+    }
+    __device__ __forceinline__ float2 resolve(const Raw& v) const
+    {
+        const float b1 = v.b1, b0 = 1.f - b1;
+        float2 o;
+        {
+            const float t0 = v.p00.x * a0 + v.p01.x * a1, t1 = v.p10.x * a0 + v.p11.x * a1;
+            o.x = (t0 * b0 + t1 * b1) * mul;
+        }
+        {
+            const float t0 = v.p00.y * a0 + v.p01.y * a1, t1 = v.p10.y * a0 + v.p11.y * a1;
+            o.y = (t0 * b0 + t1 * b1) * mul;
+        }
+        return o;
+    }
+    __device__ __forceinline__ float2 at(int r) const { return resolve(fetch(r)); }
+};
+
 template <int MH, int COLS>
 struct PCGeom {
     static constexpr int RL = 2 * MH + 6;                   // ring rows: window 2m+1, the leaving row, 2 being
@@ -294,9 +361,10 @@ struct PCGeom {
 // from the loads in slot J = t & 3, then refills that slot with step t+4 (4 rows = 4 steps of loads in flight
 // per thread).  The gather addresses depend on the flow, so the flow of step t+4 was itself fetched four
 // windows earlier (fl[J]); a one-window flow lookahead makes every window wait for a full memory latency.
-template <int MH, int COLS, int G, int J>
-__device__ __forceinline__ void produce_row(RowIn (&in)[4], float2 (&fl)[4], float (*mring)[5][COLS], const Planes& R0,
-                                            const Planes& R1, const char* FinB, int W, int H, int xc, int col, int t)
+template <int MH, int COLS, int G, int J, typename FS>
+__device__ __forceinline__ void produce_row(RowIn (&in)[4], typename FS::Raw (&fl)[4], float (*mring)[5][COLS],
+                                            const Planes& R0,
+                                            const Planes& R1, const FS& F, int W, int H, int xc, int col, int t)
 {
     constexpr int RL = PCGeom<MH, COLS>::RL;
     const int i = 2 * t + MH + G;
@@ -308,60 +376,56 @@ __device__ __forceinline__ void produce_row(RowIn (&in)[4], float2 (&fl)[4], flo
     const int slot = (i + MH + 1) % RL;      // stream index -MH-1 (first replicated row) lives in slot 0
 #pragma unroll
     for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
-    issue_row(in[J], R0, R1, W, H, xc, min(i + 8, H - 1), fl[J]);
-    fl[J] = *reinterpret_cast<const float2*>(FinB + ((unsigned)min(i + 16, H - 1) * (unsigned)W + (unsigned)xc) * 8u);
+    issue_row(in[J], R0, R1, W, H, xc, min(i + 8, H - 1), F.resolve(fl[J]));
+    fl[J] = F.fetch(min(i + 16, H - 1));
 }
 
 // Producer waves of group G: their own loop, with exactly the same barrier sequence as the consumers.
-template <int MH, int COLS, int G>
+template <int MH, int COLS, int G, typename FS>
 __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Planes& R0, const Planes& R1,
-                                              const char* FinB, int W, int H, int xc, int col, int nsteps)
+                                              const FS& F, int W, int H, int xc, int col, int nsteps)
 {
     RowIn in[4];
-    float2 fl[4];
-    auto flowAt = [&](int r) {
-        return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
-    };
+    typename FS::Raw fl[4];
+    auto flowAt = [&](int r) { return F.at(r); };
 #pragma unroll
     for (int j = 0; j < 4; j++) {   // steps 0..3 in flight
         const int r = min(2 * j + MH + G, H - 1);
         issue_row(in[j], R0, R1, W, H, xc, r, flowAt(r));
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) fl[j] = flowAt(min(2 * (j + 4) + MH + G, H - 1));   // flows of steps 4..7
+    for (int j = 0; j < 4; j++) fl[j] = F.fetch(min(2 * (j + 4) + MH + G, H - 1));   // flows of steps 4..7
     // Barrier sequence (identical in all roles): B_init, then B(s) for s = 0..nsteps-1.
     //   before B_init            step 0 is produced
     //   between B_init and B(0)  step 1                              (consumers: column sums of step 0)
     //   between B(s) and B(s+1)  step s+2                            (consumers: row sums + solve of step s,
     //                                                                 column sums of step s+1)
-    produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 0);
+    produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
     __syncthreads();
-    produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, 1);
+    produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
     for (int sb = 0; sb < nsteps; sb += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int s = sb + u;
             if (s >= nsteps) break;
             __syncthreads();
-            if (u == 0) produce_row<MH, COLS, G, 2>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
-            if (u == 1) produce_row<MH, COLS, G, 3>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
-            if (u == 2) produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
-            if (u == 3) produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, FinB, W, H, xc, col, s + 2);
+            if (u == 0) produce_row<MH, COLS, G, 2>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
+            if (u == 1) produce_row<MH, COLS, G, 3>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
+            if (u == 2) produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
+            if (u == 3) produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
         }
     }
 }
 
-template <int MH, int COLS>
+template <int MH, int COLS, typename FS>
 __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
-                                              const Planes& R1, const char* FinB, float2* Fout, int W, int H, int x0,
+                                              const Planes& R1, const FS& F, float2* Fout, int W, int H, int x0,
                                               int xc, int col, int nsteps, double scale)
 {
     using G = PCGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
     double vs[5];
-    auto flowAt = [&](int r) {
-        return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
-    };
+    auto flowAt = [&](int r) { return F.at(r); };
     {
         // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
         // ring slot of stream index i is (i + m + 1) % RL.
@@ -456,10 +520,17 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
     }
 }
 
-template <int MH, int COLS>
+// UPS: flow_in is the coarser level's flow [sh][sw][2] (ups_* describe it) instead of this level's own buffer.
+struct UpsArgs {
+    int sw, sh;
+    double scale_x, scale_y;
+    float mul;
+};
+template <int MH, int COLS, bool UPS>
 __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict__ R0b, const float* __restrict__ R1b,
                                                      size_t pair_stride, const float* __restrict__ flow_in,
-                                                     float* __restrict__ flow_out, int W, int H, int block_size)
+                                                     float* __restrict__ flow_out, int W, int H, int block_size,
+                                                     UpsArgs ups)
 {
     constexpr int SW = PCGeom<MH, COLS>::SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
@@ -477,53 +548,60 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
         R0.p[c] = reinterpret_cast<const char*>(R0b + (size_t)blockIdx.z * pair_stride + c * plane);
         R1.p[c] = reinterpret_cast<const char*>(R1b + (size_t)blockIdx.z * pair_stride + c * plane);
     }
-    const char* FinB = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * plane * 8;
+    FlowSrc<UPS> F;
+    if constexpr (UPS) {
+        F.base = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * ups.sw * ups.sh * 8;
+        F.sw = ups.sw;
+        F.sh = ups.sh;
+        F.scale_y = ups.scale_y;
+        F.mul = ups.mul;
+        lin_x(xc, ups.scale_x, ups.sw, F.sx, F.a1);
+        F.a0 = 1.f - F.a1;
+        F.c1 = min(F.sx + 1, ups.sw - 1);
+    } else {
+        F.base = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * plane * 8;
+        F.W = (unsigned)W;
+        F.xc = (unsigned)xc;
+    }
     float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)blockIdx.z * plane;
     const int nsteps = (H + 1) / 2;
     // Each role runs its own loop; all three execute one barrier before the loop and two per step.
     if (role == 0)
-        consumer_loop<MH, COLS>(mring, sv, R0, R1, FinB, Fout, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
+        consumer_loop<MH, COLS>(mring, sv, R0, R1, F, Fout, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
     else if (role == 1)
-        producer_loop<MH, COLS, 0>(mring, R0, R1, FinB, W, H, xc, col, nsteps);
+        producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
     else
-        producer_loop<MH, COLS, 1>(mring, R0, R1, FinB, W, H, xc, col, nsteps);
+        producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
 }
 
-template <int MH, int COLS>
-void launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
-                         const float* flow_in, float* flow_out, int W, int H, int winsize)
+template <int MH, bool UPS>
+void launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                       const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
-    using G = PCGeom<MH, COLS>;
+    using G = PCGeom<MH, 256>;
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in attribute (once per kernel)
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_iterate_pc<MH, COLS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_iterate_pc<MH, 256, UPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
-    hipLaunchKernelGGL((k_iterate_pc<MH, COLS>), grid, dim3(3 * COLS), G::SMEM, ctx->stream, R0, R1, pair_stride,
-                       flow_in, flow_out, W, H, winsize);
+    hipLaunchKernelGGL((k_iterate_pc<MH, 256, UPS>), grid, dim3(3 * 256), G::SMEM, ctx->stream, R0, R1, pair_stride,
+                       flow_in, flow_out, W, H, winsize, ups);
 }
 
-static int pc_cols()
+template <bool UPS>
+void launch_iterate_pc_m(nsof_ctx* ctx, int m, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                         const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
-    static int cols = 0;
-    if (!cols) {
-        const char* e = getenv("NSOF_PC_COLS");   // tuning knob: strip width of the role-specialised kernel
-        cols = e ? atoi(e) : 256;
-        if (cols != 64 && cols != 128 && cols != 256) cols = 256;
-    }
-    return cols;
-}
-
-template <int MH>
-void launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
-                       const float* flow_in, float* flow_out, int W, int H, int winsize)
-{
-    switch (pc_cols()) {
-        case 64: launch_iterate_pc_c<MH, 64>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-        case 128: launch_iterate_pc_c<MH, 128>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-        default: launch_iterate_pc_c<MH, 256>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
+    switch (m) {
+        case 1: launch_iterate_pc<1, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        case 2: launch_iterate_pc<2, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        case 3: launch_iterate_pc<3, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        case 4: launch_iterate_pc<4, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        case 5: launch_iterate_pc<5, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        case 6: launch_iterate_pc<6, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        default: launch_iterate_pc<7, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
     }
 }
 
@@ -561,15 +639,8 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
 {
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     if (use_pc(winsize / 2)) {
-        switch (winsize / 2) {
-            case 1: launch_iterate_pc<1>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-            case 2: launch_iterate_pc<2>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-            case 3: launch_iterate_pc<3>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-            case 4: launch_iterate_pc<4>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-            case 5: launch_iterate_pc<5>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-            case 6: launch_iterate_pc<6>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-            default: launch_iterate_pc<7>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
-        }
+        launch_iterate_pc_m<false>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize,
+                                   UpsArgs{});
         NSOF_HIP(ctx, hipGetLastError());
         return NSOF_OK;
     }
@@ -584,6 +655,30 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
         case 8: launch_iterate_m<8>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize); break;
         default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "fused iteration supports winsize 2..17");
     }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// First iteration of a level, reading the previous (coarser) level's flow and resampling it on the fly.
+bool nsof_iterate_upsample_supported(int winsize, int W, int H)
+{
+    return nsof_iterate_supported(winsize, W, H) && use_pc(winsize / 2);
+}
+
+int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                                 const float* coarse_flow, int sw, int sh, float mul, float* flow_out, int W, int H,
+                                 int winsize)
+{
+    if (!nsof_iterate_upsample_supported(winsize, W, H))
+        return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "fused upsample+iteration not available for winsize %d", winsize);
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    UpsArgs ups;
+    ups.sw = sw;
+    ups.sh = sh;
+    ups.scale_x = 1. / ((double)W / sw);
+    ups.scale_y = 1. / ((double)H / sh);
+    ups.mul = mul;
+    launch_iterate_pc_m<true>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, coarse_flow, flow_out, W, H, winsize, ups);
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
 }

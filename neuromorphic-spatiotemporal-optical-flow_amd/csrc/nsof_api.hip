@@ -4,6 +4,7 @@
 // coarsest level first, every level resampled from the blurred FULL-RES frame.
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "nsof_internal.h"
@@ -367,6 +368,17 @@ extern "C" int nsof_stage_iterate(nsof_ctx* ctx, int n_pairs, const float* d_R, 
                                winsize);
 }
 
+extern "C" int nsof_stage_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_coarse_flow,
+                                           int src_w, int src_h, int width, int height, int winsize, double pyr_scale,
+                                           float* d_flow_out)
+{
+    if (!ctx || !d_R || !d_coarse_flow || !d_flow_out || n_pairs < 1 || width < 1 || height < 1 || src_w < 1 || src_h < 1)
+        return NSOF_EINVAL;
+    const size_t plane = (size_t)width * height;
+    return nsof_launch_iterate_upsample(ctx, n_pairs, d_R, d_R + 5 * plane, 10 * plane, d_coarse_flow, src_w, src_h,
+                                        (float)(1. / pyr_scale), d_flow_out, width, height, winsize);
+}
+
 extern "C" int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* d_src, int sw, int sh, float* d_dst,
                                         int dw, int dh, double pyr_scale)
 {
@@ -411,7 +423,14 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
     // Each upsample and each fused iteration moves the flow to the other buffer, so the buffer the coarsest
     // level starts in is chosen such that the last iteration of level 0 writes A.
     float* fb[2] = {d_flow, dS};
-    const int flips = fused ? L * (1 + iterations) + iterations : L;
+    // The coarse-to-fine resample is folded into the first iteration of each level when the fused kernel can do
+    // it; then only iterations move the flow between the buffers.
+    // Measured on MI355X (1080p x 128 pairs): folding costs more in the producers (4 gathers + the resample per
+    // row, 168 VGPRs) than the standalone resample kernel saves (24.6 -> 25.5 ms per step), so it is opt-in.
+    static const bool fold_env = getenv("NSOF_FOLD_UPSAMPLE") != nullptr;
+    const bool fold_ups = fold_env && fused && iterations > 0 &&
+                          nsof_iterate_upsample_supported(winsize, width, height);
+    const int flips = fused ? (fold_ups ? (L + 1) * iterations : L * (1 + iterations) + iterations) : L;
     int cur = flips & 1;
 
     bool have_prev = false;
@@ -425,8 +444,11 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
             return nsof_set_error(ctx, rc, "pyramid blur kernel size %d unsupported (max %d)", ks,
                                   NSOF_MAX_BLUR_TAPS - 1);
         const size_t nk = (size_t)wk * hk;
+        bool pending_ups = false;
         if (!have_prev) {
             NSOF_HIP(ctx, hipMemsetAsync(fb[cur], 0, B * nk * 8, ctx->stream));
+        } else if (fold_ups) {
+            pending_ups = true;   // fb[cur] still holds the coarse flow (pw x ph)
         } else {
             if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, fb[cur], pw, ph, fb[cur ^ 1], wk, hk,
                                                 (float)(1. / pyr_scale))))
@@ -444,8 +466,12 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
         const float* R1 = dR + B * 5 * nk;
         if (fused) {
             for (int it = 0; it < iterations; it++) {
-                if ((rc = nsof_launch_iterate(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize)))
-                    return rc;
+                if (it == 0 && pending_ups)
+                    rc = nsof_launch_iterate_upsample(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], pw, ph,
+                                                      (float)(1. / pyr_scale), fb[cur ^ 1], wk, hk, winsize);
+                else
+                    rc = nsof_launch_iterate(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize);
+                if (rc) return rc;
                 cur ^= 1;
             }
         } else {

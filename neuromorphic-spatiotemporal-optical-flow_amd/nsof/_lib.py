@@ -32,6 +32,7 @@ SIGNATURES = {
     "nsof_stage_update_matrices": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "nsof_stage_blur_solve": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "nsof_stage_iterate": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "nsof_stage_iterate_upsample": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp]),
     "nsof_stage_flow_upsample": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _d]),
     "nsof_prof_enable": (_i, [_vp, C.c_uint]),
     "nsof_prof_collect": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),

@@ -150,6 +150,32 @@ def test_fused_iteration(ctx, oracle, torch_dev, winsize, shape):
     assert (got[0] != want).mean() < 0.01
 
 
+@pytest.mark.parametrize("winsize,pyr_scale,src,dst", [(15, 0.5, (68, 120), (135, 240)), (3, 0.6, (58, 79), (97, 131)),
+                                                       (4, 0.6, (81, 319), (135, 531))])
+def test_fused_upsample_iteration_equals_two_stages(ctx, torch_dev, oracle, winsize, pyr_scale, src, dst):
+    """k_iterate_pc<UPS> == k_flow_upsample followed by k_iterate_pc, bit for bit."""
+    import torch
+    from nsof import synth
+    h, w = dst
+    prev, nxt = synth.make_pair(21, h, w)
+    R0, R1, _ = _level_state(oracle, prev, nxt, 5, 1.2, 6)
+    rng = np.random.default_rng(4)
+    coarse = (rng.standard_normal((2,) + src + (2,)) * 2).astype(np.float32)
+    Rp = np.stack([np.stack([_planar(R0), _planar(R1)])] * 2)
+    dR, dC = _dev(torch_dev, Rp), _dev(torch_dev, coarse)
+    fine = torch.empty((2, h, w, 2), dtype=torch.float32, device=torch_dev)
+    two = torch.empty_like(fine)
+    one = torch.empty_like(fine)
+    torch.cuda.synchronize()
+    ctx.check(ctx._lib.nsof_stage_flow_upsample(ctx.ptr, 2, dC.data_ptr(), src[1], src[0], fine.data_ptr(), w, h,
+                                                pyr_scale))
+    ctx.check(ctx._lib.nsof_stage_iterate(ctx.ptr, 2, dR.data_ptr(), fine.data_ptr(), w, h, winsize, two.data_ptr()))
+    ctx.check(ctx._lib.nsof_stage_iterate_upsample(ctx.ptr, 2, dR.data_ptr(), dC.data_ptr(), src[1], src[0], w, h,
+                                                   winsize, pyr_scale, one.data_ptr()))
+    ctx.synchronize()
+    assert torch.equal(one, two)
+
+
 @pytest.mark.parametrize("pyr_scale,src,dst", [(0.5, (68, 120), (135, 240)), (0.6, (58, 79), (97, 131)),
                                                (0.5, (135, 240), (270, 480))])
 def test_flow_upsample_bit_exact(ctx, oracle, torch_dev, pyr_scale, src, dst):
