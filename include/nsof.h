@@ -83,8 +83,10 @@ int nsof_farneback_level_size(int width, int height, double pyr_scale, int level
                               int* level_width, int* level_height, int* blur_ksize, double* blur_sigma);
 
 /* Individual pipeline stages on DEVICE buffers, exposed for stage-level parity tests and
- * for the roofline benchmark.  Planar layouts: R and M are [n_img][5][h][w] float32,
- * images [n_img][h][w] float32, flow [n_img][h][w][2] float32. */
+ * for the roofline benchmark.  Layouts: images [n_img][h][w] float32; flow [n_img][h][w][2]
+ * float32; M planar [n_img][5][h][w] float32; the polynomial expansion R of ONE image is
+ * 5*h*w float32 = [h][w][4] (channels 0..3 interleaved per pixel) followed by [h][w]
+ * (channel 4), images back to back. */
 int nsof_stage_pyr_level(nsof_ctx* ctx, int n_img, const uint8_t* d_src, ptrdiff_t row_stride,
                          ptrdiff_t img_stride, int width, int height, double pyr_scale, int level, float* d_out);
 int nsof_stage_polyexp(nsof_ctx* ctx, int n_img, const float* d_img, int width, int height,

@@ -30,35 +30,30 @@ __device__ __forceinline__ int floor_f(float v)
     return i - (i > v);
 }
 
-// 32-bit byte offsets against wave-uniform plane bases keep every load in the
-// "SGPR base + VGPR offset" form (no 64-bit address arithmetic in VGPRs).
+// R of one image: [h][w][4] f32 (channels 0-3 of a pixel = one aligned 16-B access) followed by [h][w] f32
+// (channel 4).  32-bit byte offsets against wave-uniform bases keep every load in the "SGPR base + VGPR offset"
+// form.  The L1 serves 4 lanes per cycle whatever the access width, so a thread-row costs 9 loads here
+// (R0: x4 + x1; R1: 2 rows x (x4, x4, x2)) instead of 15 with planar channels.
 struct Planes {
-    const char* p[5];
+    const char* q4;   // interleaved channels 0..3
+    const char* c4;   // channel 4
 };
 struct __attribute__((packed, aligned(4))) f2u {  // two adjacent floats, only 4-byte aligned
     float a, b;
 };
-__device__ __forceinline__ float ldf(const char* base, unsigned boff)
+__device__ __forceinline__ Planes planes_of(const float* img_base, size_t plane)
 {
-    return *reinterpret_cast<const float*>(base + boff);
-}
-__device__ __forceinline__ f2u ldf2(const char* base, unsigned boff)
-{
-#ifdef NSOF_GATHER_DWORD
-    f2u r;   // two dword loads instead of one 4-byte-aligned dwordx2 (kept apart from the load combiner)
-    unsigned b2 = boff + 4u;
-    asm volatile("" : "+v"(b2));
-    r.a = *reinterpret_cast<const float*>(base + boff);
-    r.b = *reinterpret_cast<const float*>(base + b2);
-    return r;
-#else
-    return *reinterpret_cast<const f2u*>(base + boff);
-#endif
+    Planes p;
+    p.q4 = reinterpret_cast<const char*>(img_base);
+    p.c4 = reinterpret_cast<const char*>(img_base + 4 * plane);
+    return p;
 }
 
 struct RowIn {
-    float r0[5];
-    f2u top[5], bot[5];   // R1 at (y1, x1..x1+1) and (y1+1, x1..x1+1)
+    float4 z;             // R0 channels 0..3
+    float z4;             // R0 channel 4
+    float4 t0, t1, b0, b1;  // R1 channels 0..3 at (y1,x1), (y1,x1+1), (y1+1,x1), (y1+1,x1+1)
+    f2u t4, b4;           // R1 channel 4 at (y1, x1..x1+1) and (y1+1, x1..x1+1)
     float dx, dy, fx, fy;
     int inside;
 };
@@ -67,7 +62,7 @@ struct RowIn {
 __device__ __forceinline__ void issue_row(RowIn& in, const Planes& R0, const Planes& R1, int W, int H, int x, int y,
                                           float2 d)
 {
-    const unsigned pix = ((unsigned)y * (unsigned)W + (unsigned)x) * 4u;
+    const unsigned pix = (unsigned)y * (unsigned)W + (unsigned)x;
     in.dx = d.x;
     in.dy = d.y;
     float fx = x + d.x, fy = y + d.y;
@@ -76,26 +71,27 @@ __device__ __forceinline__ void issue_row(RowIn& in, const Planes& R0, const Pla
     in.fy = fy - y1;
     in.inside = (unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1);
 #if defined(NSOF_ABL) && NSOF_ABL == 3   // timing-only build: no R0 loads either
-#pragma unroll
-    for (int c = 0; c < 5; c++) in.r0[c] = d.x * (float)(c + 1) + (float)pix;
+    in.z = make_float4(d.x, d.y, d.x + 1.f, (float)pix);
+    in.z4 = d.y + 2.f;
 #else
-#pragma unroll
-    for (int c = 0; c < 5; c++) in.r0[c] = ldf(R0.p[c], pix);
+    in.z = *reinterpret_cast<const float4*>(R0.q4 + pix * 16u);
+    in.z4 = *reinterpret_cast<const float*>(R0.c4 + pix * 4u);
 #endif
     // The R1 gather is issued unconditionally, at a clamped (always valid) address when the sample falls
     // outside: a load under a lane-dependent branch cannot be counted by s_waitcnt vmcnt(N), which would
     // force every wait down to "almost nothing outstanding" and serialise the software pipeline.
     const int xs = clampi(x1, 0, W - 2), ys = clampi(y1, 0, H - 2);
-    const unsigned o = ((unsigned)ys * (unsigned)W + (unsigned)xs) * 4u;
+    const unsigned o = (unsigned)ys * (unsigned)W + (unsigned)xs;
 #if defined(NSOF_ABL) && (NSOF_ABL == 1 || NSOF_ABL == 3)   // timing-only build: no R1 gather
-#pragma unroll
-    for (int c = 0; c < 5; c++) { in.top[c].a = in.top[c].b = in.bot[c].a = in.bot[c].b = in.r0[c] + (float)o; }
+    in.t0 = in.t1 = in.b0 = in.b1 = make_float4(in.z.x + (float)o, in.z.y, in.z.z, in.z.w);
+    in.t4.a = in.t4.b = in.b4.a = in.b4.b = in.z4;
 #else
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        in.top[c] = ldf2(R1.p[c], o);
-        in.bot[c] = ldf2(R1.p[c], o + (unsigned)W * 4u);
-    }
+    in.t0 = *reinterpret_cast<const float4*>(R1.q4 + o * 16u);
+    in.t1 = *reinterpret_cast<const float4*>(R1.q4 + o * 16u + 16u);
+    in.b0 = *reinterpret_cast<const float4*>(R1.q4 + (o + (unsigned)W) * 16u);
+    in.b1 = *reinterpret_cast<const float4*>(R1.q4 + (o + (unsigned)W) * 16u + 16u);
+    in.t4 = *reinterpret_cast<const f2u*>(R1.c4 + o * 4u);
+    in.b4 = *reinterpret_cast<const f2u*>(R1.c4 + (o + (unsigned)W) * 4u);
 #endif
 }
 
@@ -107,22 +103,22 @@ __device__ __forceinline__ void matrix_from(const RowIn& in, int x, int y, int W
     if (in.inside) {
         const float fx = in.fx, fy = in.fy;
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        r2 = a00 * in.top[0].a + a01 * in.top[0].b + a10 * in.bot[0].a + a11 * in.bot[0].b;
-        r3 = a00 * in.top[1].a + a01 * in.top[1].b + a10 * in.bot[1].a + a11 * in.bot[1].b;
-        r4 = a00 * in.top[2].a + a01 * in.top[2].b + a10 * in.bot[2].a + a11 * in.bot[2].b;
-        r5 = a00 * in.top[3].a + a01 * in.top[3].b + a10 * in.bot[3].a + a11 * in.bot[3].b;
-        r6 = a00 * in.top[4].a + a01 * in.top[4].b + a10 * in.bot[4].a + a11 * in.bot[4].b;
-        r4 = (in.r0[2] + r4) * 0.5f;
-        r5 = (in.r0[3] + r5) * 0.5f;
-        r6 = (in.r0[4] + r6) * 0.25f;
+        r2 = a00 * in.t0.x + a01 * in.t1.x + a10 * in.b0.x + a11 * in.b1.x;
+        r3 = a00 * in.t0.y + a01 * in.t1.y + a10 * in.b0.y + a11 * in.b1.y;
+        r4 = a00 * in.t0.z + a01 * in.t1.z + a10 * in.b0.z + a11 * in.b1.z;
+        r5 = a00 * in.t0.w + a01 * in.t1.w + a10 * in.b0.w + a11 * in.b1.w;
+        r6 = a00 * in.t4.a + a01 * in.t4.b + a10 * in.b4.a + a11 * in.b4.b;
+        r4 = (in.z.z + r4) * 0.5f;
+        r5 = (in.z.w + r5) * 0.5f;
+        r6 = (in.z4 + r6) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = in.r0[2];
-        r5 = in.r0[3];
-        r6 = in.r0[4] * 0.5f;
+        r4 = in.z.z;
+        r5 = in.z.w;
+        r6 = in.z4 * 0.5f;
     }
-    r2 = (in.r0[0] - r2) * 0.5f;
-    r3 = (in.r0[1] - r3) * 0.5f;
+    r2 = (in.z.x - r2) * 0.5f;
+    r3 = (in.z.y - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     if ((unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10)) {
@@ -158,12 +154,8 @@ __global__ __launch_bounds__(256, 2) void k_iterate(const float* __restrict__ R0
     const int x0 = blockIdx.x * SW;
     const int xc = clampi(x0 - MH + tid, 0, W - 1);
     const size_t plane = (size_t)W * H;
-    Planes R0, R1;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        R0.p[c] = reinterpret_cast<const char*>(R0b + (size_t)blockIdx.z * pair_stride + c * plane);
-        R1.p[c] = reinterpret_cast<const char*>(R1b + (size_t)blockIdx.z * pair_stride + c * plane);
-    }
+    const Planes R0 = planes_of(R0b + (size_t)blockIdx.z * pair_stride, plane);
+    const Planes R1 = planes_of(R1b + (size_t)blockIdx.z * pair_stride, plane);
     const char* FinB = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * plane * 8;
     auto flowAt = [&](int r) {   // flow_in at (row r, this thread's column)
         return *reinterpret_cast<const float2*>(FinB + ((unsigned)r * (unsigned)W + (unsigned)xc) * 8u);
@@ -542,12 +534,8 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
     const int x0 = blockIdx.x * SW;
     const int xc = clampi(x0 - MH + col, 0, W - 1);
     const size_t plane = (size_t)W * H;
-    Planes R0, R1;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        R0.p[c] = reinterpret_cast<const char*>(R0b + (size_t)blockIdx.z * pair_stride + c * plane);
-        R1.p[c] = reinterpret_cast<const char*>(R1b + (size_t)blockIdx.z * pair_stride + c * plane);
-    }
+    const Planes R0 = planes_of(R0b + (size_t)blockIdx.z * pair_stride, plane);
+    const Planes R1 = planes_of(R1b + (size_t)blockIdx.z * pair_stride, plane);
     FlowSrc<UPS> F;
     if constexpr (UPS) {
         F.base = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * ups.sw * ups.sh * 8;

@@ -7,7 +7,9 @@
 // -ffp-contract=off so that a*b+c stays two roundings unless fma() is written explicitly.
 //
 // All kernels are HBM/L2-bound stencils: no MFMA.  Layouts: images [n][h][w] f32,
-// R and M planar [n][5][h][w] f32 (coalesced 256 B per wave per plane), flow [n][h][w][2].
+// R per image: [h][w][4] f32 (channels 0-3 interleaved: one 16-B access per pixel) followed by [h][w] f32 (channel 4)
+// -- the L1 serves 4 lanes per cycle whatever the access width, so the gather of the matrix update wants few, wide
+// loads.  M planar [n][5][h][w] f32 (unfused path only).  Flow [n][h][w][2].
 #include <cstdlib>
 
 #include "nsof_internal.h"
@@ -461,6 +463,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
     // The 2N double-precision taps would not fit the scalar register file next to the float taps (SGPR
     // spills cost more than the arithmetic); they live in LDS and are re-read (broadcast) once per step.
     __shared__ double stap[2][N + 1];
+    __shared__ float4 st[4][256];   // per-wave transpose buffer for the interleaved channel-0..3 stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid <= N) {
@@ -521,18 +524,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
         const int yo = y + wave;
         const int xo = x0 + 4 * lane;
         if (4 * lane < G::SW && yo < ye && xo < W) {
-            const unsigned obase = ((unsigned)yo * (unsigned)W + (unsigned)xo) * 4u;
-            const bool vec = (W & 3) == 0;
-            auto store4 = [&](int c, const float (&o)[4]) {
-                char* dst = Rb + (obase + (unsigned)c * plane * 4u);
-                if (vec) {
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int p = 0; p < 4; p++)
-                        if (xo + p < W) reinterpret_cast<float*>(dst)[p] = o[p];
-                }
-            };
+            const unsigned opix = (unsigned)yo * (unsigned)W + (unsigned)xo;
             auto load_row = [&](int a, float (&v)[4 * G::NV]) {
                 const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][a][wave][4 * lane]);
 #pragma unroll
@@ -542,8 +534,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                 }
             };
             double t03[4];  // b1 * ig03, shared by the xx and yy outputs
+            float o0[4], o1[4], o2[4], o3[4], o4[4];
             {
-                float v[4 * G::NV], o1[4], o3[4];
+                float v[4 * G::NV];
                 double dg[N + 1], dxxg[N + 1];
 #pragma unroll
                 for (int k = 1; k <= N; k++) {
@@ -567,11 +560,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                     o1[p] = (float)(a2 * tp.ig11);
                     o3[p] = (float)(t03[p] + a4 * tp.ig33);
                 }
-                store4(1, o1);
-                store4(3, o3);
             }
             {
-                float v[4 * G::NV], o0[4], o4[4];
+                float v[4 * G::NV];
                 load_row(1, v);
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -586,11 +577,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                     o0[p] = (float)(a3 * tp.ig11);
                     o4[p] = (float)(a6 * tp.ig55);
                 }
-                store4(0, o0);
-                store4(4, o4);
             }
             {
-                float v[4 * G::NV], o2[4];
+                float v[4 * G::NV];
                 load_row(2, v);
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -600,10 +589,34 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                     for (int k = 1; k <= N; k++) a5 += (double)((v[c + k] + v[c - k]) * tp.g[k]);
                     o2[p] = (float)(t03[p] + a5 * tp.ig33);
                 }
-                store4(2, o2);
+            }
+            // channel 4 of the lane's 4 pixels: one 16-B store
+            float* c4 = reinterpret_cast<float*>(Rb) + 4u * plane + opix;
+            if ((W & 3) == 0) {
+                *reinterpret_cast<float4*>(c4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    if (xo + p < W) c4[p] = o4[p];
+            }
+            // channels 0-3: a lane holds 4 consecutive pixels x 16 B; stored as is, one instruction would write 16 B
+            // per lane at a 64-B stride.  Transpose through LDS (per wave) so that every store instruction writes
+            // 64 consecutive pixels = 1 KiB contiguous.
+#pragma unroll
+            for (int p = 0; p < 4; p++) st[wave][4 * lane + p] = make_float4(o0[p], o1[p], o2[p], o3[p]);
+        }
+        {
+            // every lane of the wave takes part (lanes beyond the strip read slots nobody wrote, and do not store)
+            const int yo2 = y + wave;
+            float4* q4 = reinterpret_cast<float4*>(Rb) + (unsigned)yo2 * (unsigned)W + (unsigned)x0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int px = 64 * k + lane;   // pixel within the strip row
+                const float4 v = st[wave][px];
+                if (px < G::SW && yo2 < ye && x0 + px < W) q4[px] = v;
             }
         }
-        // no second barrier: the next step writes the other LDS buffer
+        // no second barrier: the next step writes the other LDS buffer (st is private to a wave)
     }
 }
 
@@ -630,23 +643,28 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict
     float r2, r3, r4, r5, r6;
     if ((unsigned)x1 < (unsigned)(W - 1) && (unsigned)y1 < (unsigned)(H - 1)) {
         const float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float* p = R1 + (size_t)y1 * W + x1;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1]; p += plane;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[W] + a11 * p[W + 1];
-        r4 = (R0[2 * plane + pix] + r4) * 0.5f;
-        r5 = (R0[3 * plane + pix] + r5) * 0.5f;
+        const float4* q = reinterpret_cast<const float4*>(R1) + (size_t)y1 * W + x1;
+        const float* c4 = R1 + 4 * plane + (size_t)y1 * W + x1;
+        const float4 t0 = q[0], t1 = q[1], b0 = q[W], b1 = q[W + 1];
+        r2 = a00 * t0.x + a01 * t1.x + a10 * b0.x + a11 * b1.x;
+        r3 = a00 * t0.y + a01 * t1.y + a10 * b0.y + a11 * b1.y;
+        r4 = a00 * t0.z + a01 * t1.z + a10 * b0.z + a11 * b1.z;
+        r5 = a00 * t0.w + a01 * t1.w + a10 * b0.w + a11 * b1.w;
+        r6 = a00 * c4[0] + a01 * c4[1] + a10 * c4[W] + a11 * c4[W + 1];
+        const float4 z = reinterpret_cast<const float4*>(R0)[pix];
+        r4 = (z.z + r4) * 0.5f;
+        r5 = (z.w + r5) * 0.5f;
         r6 = (R0[4 * plane + pix] + r6) * 0.25f;
+        r2 = (z.x - r2) * 0.5f;
+        r3 = (z.y - r3) * 0.5f;
     } else {
-        r2 = r3 = 0.f;
-        r4 = R0[2 * plane + pix];
-        r5 = R0[3 * plane + pix];
+        const float4 z = reinterpret_cast<const float4*>(R0)[pix];
+        r4 = z.z;
+        r5 = z.w;
         r6 = R0[4 * plane + pix] * 0.5f;
+        r2 = (z.x - 0.f) * 0.5f;
+        r3 = (z.y - 0.f) * 0.5f;
     }
-    r2 = (R0[pix] - r2) * 0.5f;
-    r3 = (R0[plane + pix] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     if ((unsigned)(x - 5) >= (unsigned)(W - 10) || (unsigned)(y - 5) >= (unsigned)(H - 10)) {

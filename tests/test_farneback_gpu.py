@@ -28,8 +28,13 @@ def _dev(torch_dev, a):
     return t
 
 
-def _planar(aos):  # (h,w,5) -> (5,h,w)
+def _planar(aos):  # (h,w,5) -> (5,h,w)   (layout of M)
     return np.ascontiguousarray(np.moveaxis(aos, -1, 0))
+
+
+def _rlayout(aos):
+    """Oracle R (h,w,5) -> device layout of one image: [h][w][4] (channels 0..3) then [h][w] (channel 4), flat."""
+    return np.concatenate([np.ascontiguousarray(aos[..., :4]).ravel(), np.ascontiguousarray(aos[..., 4]).ravel()])
 
 
 @pytest.fixture(scope="module")
@@ -69,12 +74,12 @@ def test_polyexp_bit_exact(ctx, oracle, torch_dev, n, sigma, shape):
     rng = np.random.default_rng(n * 1000 + shape[0])
     imgs = (rng.random((3,) + shape) * 255).astype(np.float32)
     d = _dev(torch_dev, imgs)
-    out = torch.empty((3, 5) + shape, dtype=torch.float32, device=torch_dev)
+    out = torch.empty((3, 5 * shape[0] * shape[1]), dtype=torch.float32, device=torch_dev)
     ctx.check(ctx._lib.nsof_stage_polyexp(ctx.ptr, 3, d.data_ptr(), shape[1], shape[0], n, sigma, out.data_ptr()))
     ctx.synchronize()
     got = out.cpu().numpy()
     for i in range(3):
-        want = _planar(oracle.polyexp(imgs[i], n, sigma))
+        want = _rlayout(oracle.polyexp(imgs[i], n, sigma))
         assert np.array_equal(got[i], want), f"image {i}: max ulp {ulp_diff(got[i], want).max()}"
 
 
@@ -95,7 +100,7 @@ def test_update_matrices_bit_exact(ctx, oracle, torch_dev, frames, shape):
     prev, nxt = frames[shape]
     R0, R1, flow = _level_state(oracle, prev, nxt, 5, 1.2, 5)
     want = _planar(oracle.update_matrices(R0, R1, flow))
-    Rp = np.stack([np.stack([_planar(R0), _planar(R1)])] * 2)  # 2 pairs
+    Rp = np.stack([np.stack([_rlayout(R0), _rlayout(R1)])] * 2)  # 2 pairs
     flows = np.stack([flow, flow])
     dR, dF = _dev(torch_dev, Rp), _dev(torch_dev, flows)
     out = torch.empty((2, 5, h, w), dtype=torch.float32, device=torch_dev)
@@ -137,7 +142,7 @@ def test_fused_iteration(ctx, oracle, torch_dev, winsize, shape):
     R0, R1, flow = _level_state(oracle, prev, nxt, 5, 1.2, 6)
     M = oracle.update_matrices(R0, R1, flow)
     want, _ = oracle.update_flow_blur(R0, R1, flow, M, winsize, False)
-    Rp = np.stack([np.stack([_planar(R0), _planar(R1)])] * 2)
+    Rp = np.stack([np.stack([_rlayout(R0), _rlayout(R1)])] * 2)
     dR, dF = _dev(torch_dev, Rp), _dev(torch_dev, np.stack([flow, flow]))
     out = torch.zeros((2, h, w, 2), dtype=torch.float32, device=torch_dev)
     torch.cuda.synchronize()
@@ -161,7 +166,7 @@ def test_fused_upsample_iteration_equals_two_stages(ctx, torch_dev, oracle, wins
     R0, R1, _ = _level_state(oracle, prev, nxt, 5, 1.2, 6)
     rng = np.random.default_rng(4)
     coarse = (rng.standard_normal((2,) + src + (2,)) * 2).astype(np.float32)
-    Rp = np.stack([np.stack([_planar(R0), _planar(R1)])] * 2)
+    Rp = np.stack([np.stack([_rlayout(R0), _rlayout(R1)])] * 2)
     dR, dC = _dev(torch_dev, Rp), _dev(torch_dev, coarse)
     fine = torch.empty((2, h, w, 2), dtype=torch.float32, device=torch_dev)
     two = torch.empty_like(fine)
