@@ -158,6 +158,12 @@ int nsof_accum_read_resistance(nsof_accum* acc, int which, float* r_out);
 /* Snapshots taken so far; copy them ([count][H][W] float32) to HOST and clear the ring. */
 int64_t nsof_accum_snapshot_count(const nsof_accum* acc);
 int nsof_accum_read_snapshots(nsof_accum* acc, int which, float* out, int64_t max_count);
+/* Frame-driven variant of the same device ODE (simulation/simulationcode_v4_transistor_uav.m:146-227,332-347),
+ * float64: imgs = HOST compressed frames [n_frames][H][W] in [0,1]; per frame pair the drive voltage comes
+ * from |a-b|*256 through the piecewise map (th1, th2) and modulatefunc, followed by n_sub_steps Euler sub-steps
+ * of dt/n_sub_steps.  w_out [H][W]; res_out [n_frames][H][W] (initial array, then one snapshot per pair). */
+int nsof_accum_frames_f64(nsof_ctx* ctx, const double* imgs, int n_frames, int height, int width, double dt,
+                          int n_sub_steps, double th1, double th2, double* w_out, double* res_out);
 /* slice_indices() of event_mem_sim.py:78-83 on a HOST timestamp array: returns the number
  * of bounds and fills idx (if not NULL) with up to cap entries. */
 int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t slice_us, int64_t* idx, int64_t cap);

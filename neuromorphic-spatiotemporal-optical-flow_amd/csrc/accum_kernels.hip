@@ -173,6 +173,32 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
     }
 }
 
+// Frame-driven variant (/root/reference/simulation/simulationcode_v4_transistor_uav.m:146-227, 332-347), float64:
+// drive voltage from the absolute difference of two compressed frames, then n_sub Euler sub-steps of the same ODE.
+__device__ __forceinline__ double frame_update(double w, double V, double dt)
+{
+    double dwdt = 0.0;
+    if (V < -0.2) dwdt = 51.03 * (V / -0.2 - 1) * pow(1 - w * 0.8, 3.10);
+    else if (V > 0.1) dwdt = -2.91 * (V / 0.1 - 1) * pow(1 - w * 0.2, -5.12);
+    const double nw = w + dwdt * dt;
+    return nw < 0 ? 0 : (nw > 1 ? 1 : nw);
+}
+
+__global__ __launch_bounds__(64) void k_frame_step(const double* __restrict__ a, const double* __restrict__ b,
+                                                    double* __restrict__ w, double* __restrict__ res, size_t n,
+                                                    double dts, int n_sub, double th1, double th2, double lambda)
+{
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const double d = fabs(a[i] * 256 - b[i] * 256);
+    double V = d > th1 ? (d + 4) * 0.75 : (d - 5.5) * 0.6;   // func2 == func3 in the source
+    V = V > 0 ? -(0.3 * V + 0) : (V < 0 ? -(3 * V + -3) : 0.0);
+    double ww = w[i];
+    for (int s = 0; s < n_sub; s++) ww = frame_update(ww, V, dts);
+    w[i] = ww;
+    res[i] = RON / exp(-lambda * (1 - ww));
+}
+
 inline int grid_for(size_t n, int cap = 4096)
 {
     size_t g = (n + 255) / 256;
@@ -501,4 +527,41 @@ extern "C" int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t 
         }
     }
     return nb;
+}
+
+// Frame-driven accumulator on HOST arrays: imgs float64 [n_frames][H][W] (compressed frames in [0,1]);
+// w_out float64 [H][W]; res_out float64 [n_frames][H][W] (initial state, then one snapshot per frame pair).
+extern "C" int nsof_accum_frames_f64(nsof_ctx* ctx, const double* imgs, int n_frames, int height, int width, double dt,
+                                     int n_sub_steps, double th1, double th2, double* w_out, double* res_out)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (!imgs || !w_out || !res_out || n_frames < 1 || height < 1 || width < 1 || n_sub_steps < 1)
+        return nsof_set_error(ctx, NSOF_EINVAL, "bad frame-accumulator arguments");
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)height * width;
+    double *d_img = nullptr, *d_w = nullptr, *d_res = nullptr;
+    int rc = accum_alloc(ctx, (void**)&d_img, (size_t)n_frames * npx * 8);
+    if (!rc) rc = accum_alloc(ctx, (void**)&d_w, npx * 8);
+    if (!rc) rc = accum_alloc(ctx, (void**)&d_res, (size_t)n_frames * npx * 8);
+    if (!rc) {
+        const double lambda = std::log(ROFF / RON);
+        std::vector<double> init(npx, 0.5), r0(npx, RON / std::exp(-lambda * 0.5));
+        hipError_t e = hipMemcpyAsync(d_img, imgs, (size_t)n_frames * npx * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_w, init.data(), npx * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_res, r0.data(), npx * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        for (int f = 0; f + 1 < n_frames && e == hipSuccess; f++) {
+            hipLaunchKernelGGL(k_frame_step, dim3((unsigned)((npx + 63) / 64)), dim3(64), 0, ctx->stream,
+                               d_img + (size_t)f * npx, d_img + (size_t)(f + 1) * npx, d_w, d_res + (size_t)(f + 1) * npx,
+                               npx, dt / n_sub_steps, n_sub_steps, th1, th2, lambda);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(w_out, d_w, npx * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(res_out, d_res, (size_t)n_frames * npx * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = nsof_set_error(ctx, NSOF_EDEVICE, "frame accumulator: %s", hipGetErrorString(e));
+    }
+    hipFree(d_img); hipFree(d_w); hipFree(d_res);
+    return rc;
 }

@@ -17,7 +17,7 @@ from .context import Context, default_context  # noqa: F401
 from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_levels, farneback_batch,  # noqa: F401
                         install, level_size, uninstall)
 from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, load_events, resistance_exp,  # noqa: F401
-                          simulate, slice_indices, update_state)
+                          simulate, simulate_frames, slice_indices, update_state)
 
 from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, gating_maps,  # noqa: F401,E402
                      opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)

@@ -202,6 +202,24 @@ def simulate(events, version=1, slice_us=1_000, active_v=-8.0, silent_v=0.0, sav
     return out
 
 
+def simulate_frames(compressed_images, dt=0.0005, n_sub_steps=1000, th1=0.7, th2=1.5, *, ctx=None):
+    """Frame-driven accumulator of /root/reference/simulation/simulationcode_v4_transistor_uav.m
+    (``simulate_memristor_array``, :187-227): ``compressed_images`` float64 [n][H][W] in [0,1] (the output of the
+    script's Lanczos ``compress_image``).  Returns ``(w_array, resistances_over_time)`` with the initial snapshot
+    first, as the script stores them.  uav: th1=0.7, th2=1.5; vehicle: th1=2."""
+    ctx = ctx or default_context()
+    imgs = np.ascontiguousarray(compressed_images, np.float64)
+    if imgs.ndim != 3:
+        raise NsofValueError("compressed_images must be [n][H][W]")
+    n, H, W = imgs.shape  # noqa: N806
+    w = np.empty((H, W), np.float64)
+    res = np.empty((n, H, W), np.float64)
+    ctx.check(ctx._lib.nsof_accum_frames_f64(ctx.ptr, imgs.ctypes.data, n, H, W, float(dt), int(n_sub_steps),
+                                             float(th1), float(th2), w.ctypes.data, res.ctypes.data),
+              "simulate_frames")
+    return w, res
+
+
 def _save_outputs(prefix, out, version, slice_us, polarity, h5_path):
     """File set of event_mem_sim.py:289-322 (npz keys ``w_final`` / ``resistances``; json.gz metadata)."""
     np.savez_compressed(prefix.with_suffix(f".V{version}.npz"), w_final=out["w_final"],

@@ -155,3 +155,53 @@ int nsof_ref_accum_simulate(const int16_t* x, const int16_t* y, const int8_t* po
     free(idx); free(Va); free(Vb); free(ok_a); free(ok_b); free(elig);
     return rc;
 }
+
+/* ---- frame-driven variant: /root/reference/simulation/simulationcode_v4_transistor_uav.m -------------------
+ *   calculate_difference_matrix + func1/2/3  :146-171     modulatefunc :332-347
+ *   update_state (scalar, float64)           :173-184     simulate_memristor_array :187-227
+ *   calculate_resistances_exp                :233-236
+ * PARITY UNPINNED: there is no MATLAB/Octave in the build container and the reference ships no outputs of this
+ * script; the restatement follows the source text.  `imgs` are the already compressed frames (doubles in [0,1],
+ * the output of compress_image :111-121 -- imresize(...,'lanczos3') itself is not restated).
+ * res holds n_frames snapshots: the initial array, then one after every frame pair. */
+static double frame_update(double w, double V, double dt)
+{
+    double dwdt = 0.0;
+    if (V < -0.2) dwdt = 51.03 * (V / -0.2 - 1) * pow(1 - w * 0.8, 3.10);
+    else if (V > 0.1) dwdt = -2.91 * (V / 0.1 - 1) * pow(1 - w * 0.2, -5.12);
+    double nw = w + dwdt * dt;
+    return nw < 0 ? 0 : (nw > 1 ? 1 : nw);
+}
+
+double nsof_ref_frame_drive(double a, double b, double th1, double th2)
+{
+    double d = fabs(a * 256 - b * 256), V;
+    if (d > th2) V = (d + 4) * 0.75;
+    else if (d > th1) V = (d + 4) * 0.75;
+    else V = (d - 5.5) * 0.6;
+    /* modulatefunc: undefined for V == 0 in the source (v_mod unset); 0 is returned here */
+    if (V > 0) return -(0.3 * V + 0);
+    if (V < 0) return -(3 * V + -3);
+    return 0.0;
+}
+
+int nsof_ref_accum_frames(const double* imgs, int n_frames, int H, int W, double dt, int n_sub, double th1,
+                          double th2, double* w, double* res)
+{
+    if (n_frames < 1 || H < 1 || W < 1 || n_sub < 1) return -1;
+    const size_t npx = (size_t)H * W;
+    const double lambda = log(ROFF / RON), dts = dt / n_sub;
+    for (size_t i = 0; i < npx; i++) { w[i] = 0.5; res[i] = RON / exp(-lambda * (1 - w[i])); }
+    for (int f = 0; f + 1 < n_frames; f++) {
+        const double* a = imgs + (size_t)f * npx;
+        const double* b = a + npx;
+        for (size_t i = 0; i < npx; i++) {
+            const double v = nsof_ref_frame_drive(a[i], b[i], th1, th2);
+            double ww = w[i];
+            for (int s = 0; s < n_sub; s++) ww = frame_update(ww, v, dts);
+            w[i] = ww;
+            res[(size_t)(f + 1) * npx + i] = RON / exp(-lambda * (1 - ww));
+        }
+    }
+    return 0;
+}

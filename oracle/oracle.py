@@ -68,6 +68,21 @@ def _bind_accum(l):
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
 
 
+def accum_frames(imgs, dt=5e-4, n_sub=1000, th1=0.7, th2=1.5):
+    """Frame-driven variant (simulation/simulationcode_v4_transistor_uav.m). imgs: float64 [n][H][W] in [0,1]."""
+    imgs = np.ascontiguousarray(imgs, np.float64)
+    n, H, W = imgs.shape
+    w = np.empty((H, W), np.float64)
+    res = np.empty((n, H, W), np.float64)
+    l = lib()
+    l.nsof_ref_accum_frames.restype = C.c_int
+    l.nsof_ref_accum_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p]
+    _chk(l.nsof_ref_accum_frames(imgs.ctypes.data, n, H, W, dt, n_sub, th1, th2, w.ctypes.data, res.ctypes.data),
+         "accum_frames")
+    return w, res
+
+
 def _chk(rc, what):
     if rc != 0:
         raise RuntimeError(f"oracle {what} failed: rc={rc}")

@@ -116,3 +116,19 @@ def test_event_outside_sensor_is_rejected(nsof_lib, ctx):
     t = np.array([0, 10], np.int64)
     with pytest.raises(nsof_lib.error):
         nsof_lib.simulate((x, y, p, t), version=1, sensor_size=(64, 64), ctx=ctx)
+
+
+def test_frame_driven_variant_vs_oracle(nsof_lib, ctx, oracle):
+    """float64, 1000 Euler sub-steps per frame pair (simulation/simulationcode_v4_transistor_uav.m): the device's
+    double pow differs from libm's in the last bits, hence 1e-9 on w after 4000 sub-steps."""
+    rng = np.random.default_rng(3)
+    for shape in [(4, 4), (9, 31)]:
+        imgs = rng.random((5,) + shape)
+        imgs[3] = imgs[2]
+        w, res = nsof_lib.simulate_frames(imgs, ctx=ctx)
+        wr, rr = oracle.accum_frames(imgs)
+        assert w.shape == shape and res.shape == (5,) + shape
+        assert np.abs(w - wr).max() < 1e-9
+        assert (np.abs(res - rr) / rr).max() < 1e-9
+    w2, _ = nsof_lib.simulate_frames(imgs, th1=2.0, n_sub_steps=10, ctx=ctx)   # vehicle variant, fast simulation
+    assert np.abs(w2 - oracle.accum_frames(imgs, n_sub=10, th1=2.0)[0]).max() < 1e-12

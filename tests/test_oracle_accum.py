@@ -65,3 +65,34 @@ def test_simulate_vs_reference(oracle, name):
     if "w_final_b" in d:
         assert np.abs(out["w_final_b"] - d["w_final_b"]).max() <= 3e-7
         assert (np.abs(out["resistances_b"][idx] - d["resistances_b"]) / d["resistances_b"]).max() <= 1e-6
+
+
+def test_frame_driven_variant_properties(oracle):
+    """simulation/*.m restatement (parity unpinned: no MATLAB): checked against the source's own structure."""
+    rng = np.random.default_rng(1)
+    imgs = rng.random((5, 4, 4))
+    imgs[2] = imgs[1]                        # an unchanged frame pair: every pixel leaks
+    w, res = oracle.accum_frames(imgs, n_sub=1000)
+    assert res.shape == (5, 4, 4) and np.allclose(res[0], np.sqrt(163305.0 * 2104377.0))   # w = 0.5 initially
+    assert np.all((w >= 0) & (w <= 1))
+    lam = np.log(2104377 / 163305)
+    assert np.allclose(res[-1], 163305 / np.exp(-lam * (1 - w)), rtol=1e-12)
+    # unchanged pixels get d = 0 -> V = -3.3 -> v_mod = +12.9 > von: w decreases (leak)
+    w1, r1 = oracle.accum_frames(imgs[1:3], n_sub=1000)
+    assert np.all(w1 < 0.5)
+    # strongly changed pixels (d > th2) get v_mod < voff: w increases
+    a = np.zeros((2, 2, 2)); a[1] = 0.5
+    w2, _ = oracle.accum_frames(a, n_sub=1000)
+    assert np.all(w2 > 0.5)
+    # sub-stepping converges: 1000 and 2000 sub-steps agree to 1e-4, 1 and 1000 differ visibly
+    wa, _ = oracle.accum_frames(imgs, n_sub=2000)
+    assert np.abs(wa - w).max() < 1e-4
+    # the float64 ODE with ONE sub-step of dt equals the event simulator's float32 update_state
+    g = np.load(golden_path("accum_update_state.npz"))
+    from oracle import oracle as O
+    l = O.lib()
+    import ctypes as C
+    l.nsof_ref_frame_drive.restype = C.c_double
+    l.nsof_ref_frame_drive.argtypes = [C.c_double] * 4
+    assert abs(l.nsof_ref_frame_drive(0.0, 0.0, 0.7, 1.5) - 12.9) < 1e-12      # -(3*(-3.3) - 3)
+    assert abs(l.nsof_ref_frame_drive(0.0, 0.5, 0.7, 1.5) - (-0.3 * 132 * 0.75)) < 1e-12
