@@ -176,9 +176,11 @@ static double frame_update(double w, double V, double dt)
 double nsof_ref_frame_drive(double a, double b, double th1, double th2)
 {
     double d = fabs(a * 256 - b * 256), V;
-    if (d > th2) V = (d + 4) * 0.75;
-    else if (d > th1) V = (d + 4) * 0.75;
-    else V = (d - 5.5) * 0.6;
+    /* three masked assignments in the source, the last one (diff <= th1 -> func1) wins where masks overlap
+     * (the vehicle script has th1 = 2 > th2 = 1.5) */
+    if (d <= th1) V = (d - 5.5) * 0.6;          /* func1 */
+    else if (d <= th2) V = (d + 4) * 0.75;      /* func2 */
+    else V = (d + 4) * 0.75;                    /* func3 */
     /* modulatefunc: undefined for V == 0 in the source (v_mod unset); 0 is returned here */
     if (V > 0) return -(0.3 * V + 0);
     if (V < 0) return -(3 * V + -3);
