@@ -562,20 +562,31 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
         producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
 }
 
-template <int MH, bool UPS>
-void launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
-                       const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
+template <int MH, int COLS, bool UPS>
+void launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                         const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
-    using G = PCGeom<MH, 256>;
+    using G = PCGeom<MH, COLS>;
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in attribute (once per kernel)
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_iterate_pc<MH, 256, UPS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_iterate_pc<MH, COLS, UPS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         attr_set = true;
     }
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
-    hipLaunchKernelGGL((k_iterate_pc<MH, 256, UPS>), grid, dim3(3 * 256), G::SMEM, ctx->stream, R0, R1, pair_stride,
+    hipLaunchKernelGGL((k_iterate_pc<MH, COLS, UPS>), grid, dim3(3 * COLS), G::SMEM, ctx->stream, R0, R1, pair_stride,
                        flow_in, flow_out, W, H, winsize, ups);
+}
+
+template <int MH, bool UPS>
+void launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                       const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
+{
+    static const bool narrow = getenv("NSOF_PC_COLS128") != nullptr;   // tuning experiment: 2 blocks of 128 columns per CU
+    if (!UPS && narrow)
+        launch_iterate_pc_c<MH, 128, false>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+    else
+        launch_iterate_pc_c<MH, 256, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
 }
 
 template <bool UPS>

@@ -299,6 +299,8 @@ static int check_params(nsof_ctx* ctx, int width, int height, double pyr_scale, 
                         int iterations, int poly_n, int flags)
 {
     if (width < 1 || height < 1) return nsof_set_error(ctx, NSOF_ESHAPE, "empty image %dx%d", width, height);
+    if ((long long)width * height > (1ll << 27))   // kernels address one image with 32-bit byte offsets
+        return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "image %dx%d exceeds 2^27 pixels", width, height);
     if (!(pyr_scale > 0) || !(pyr_scale < 1))
         return nsof_set_error(ctx, NSOF_EINVAL, "pyr_scale=%g must be in (0,1)", pyr_scale);
     if (winsize == 1)  // upstream's running sums are ill-formed for a 1x1 window (m = 0); never used by the reference
@@ -396,6 +398,8 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
 {
     if (!ctx) return NSOF_EINVAL;
     if (!d_prev || !d_next || !d_flow || n_pairs < 1) return nsof_set_error(ctx, NSOF_EINVAL, "null buffer or n_pairs<1");
+    if (n_pairs > 32767)   // 2*n_pairs images go on gridDim.z
+        return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "n_pairs=%d exceeds 32767 per call", n_pairs);
     int rc = check_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
     if (rc) return rc;
     if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
