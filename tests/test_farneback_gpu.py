@@ -310,3 +310,23 @@ def test_large_window_takes_unfused_path(nsof_lib, ctx, oracle, frames):
     p = (0.5, 2, 25, 2, 5, 1.2, 0)
     got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *p, ctx=ctx)
     assert np.abs(got - oracle.farneback(prev, nxt, *p)).max() <= PIPE_TOL
+
+
+def test_fuzz_parameters_vs_oracle(nsof_lib, ctx, oracle):
+    """Seeded sweep over shapes and parameter combinations (exercises every templated kernel instance: poly_n 1..10,
+    window half-widths 1..8 and the unfused path beyond, blur sizes 3..31 incl. the runtime-size pyramid kernels)."""
+    from nsof import synth
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(48):
+        h, w = int(rng.integers(33, 260)), int(rng.integers(33, 420))
+        p = (float(rng.choice([0.5, 0.6, 0.75, 0.8])), int(rng.integers(0, 6)), int(rng.integers(2, 20)),
+             int(rng.integers(0, 4)), int(rng.integers(1, 11)), float(rng.choice([0.0, 0.8, 1.1, 1.5, 2.0])), 0)
+        prev, nxt = synth.make_pair(1000 + case, h, w, shift=(float(rng.uniform(-4, 4)), float(rng.uniform(-4, 4))),
+                                    rot_deg=float(rng.uniform(-1, 1)))
+        got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *p, ctx=ctx)
+        want = oracle.farneback(prev, nxt, *p)
+        err = float(np.abs(got - want).max())
+        worst = max(worst, err)
+        assert err <= PIPE_TOL * max(1.0, float(np.abs(want).max()) / 10), (case, (h, w), p, err)
+    assert worst <= 1e-4
