@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--params", choices=["A", "B", "C"], default="A")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--mode", choices=["pairs", "sequence"], default="pairs",
+                    help="pairs (headline): independent frame pairs; sequence: pairs+1 consecutive frames, the "
+                         "per-frame work is shared between neighbouring pairs (nsof_farneback_u8_sequence_dev)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,8 +138,14 @@ def main():
     flow = torch.empty((n, h, w, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize(dev)
 
+    if args.mode == "sequence":   # pairs+1 frames: frame i+1 = "next" of pair i = "prev" of pair i+1
+        frames = torch.cat([prevs, nexts[-1:]], 0).contiguous()
+
     def step():
-        nsof.farneback_batch(prevs, nexts, flow, n, h, w, p, ctx=ctx)
+        if args.mode == "sequence":
+            nsof.farneback_sequence(frames, flow, n + 1, h, w, p, ctx=ctx)
+        else:
+            nsof.farneback_batch(prevs, nexts, flow, n, h, w, p, ctx=ctx)
 
     def barrier():
         if use_dist:
@@ -191,7 +200,7 @@ def main():
             "config": {"workload": f"{w}x{h} u8 frame pairs, Farneback params {args.params} "
                                    f"(pyr_scale={p.pyr_scale}, levels={p.levels}, winsize={p.winsize}, "
                                    f"iterations={p.iterations}, poly_n={p.poly_n}, poly_sigma={p.poly_sigma}, flags=0)",
-                       "pairs_per_gpu_per_step": n, "global_pairs_per_step": n * world,
+                       "mode": args.mode, "pairs_per_gpu_per_step": n, "global_pairs_per_step": n * world,
                        "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
         }
         if prof:
@@ -209,7 +218,7 @@ def main():
                     if ent is not None:
                         out[key]["traffic"] = int(out[key]["algorithmic_bytes_per_launch"] *
                                                   ent["traffic_over_algorithmic"])
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         print(json.dumps(out))
     if use_dist:

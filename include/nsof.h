@@ -77,6 +77,17 @@ int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs,
                                 double pyr_scale, int levels, int winsize, int iterations,
                                 int poly_n, double poly_sigma, int flags);
 
+/* Sequence twin: n_frames consecutive frames already in HBM, d_frames uint8 [n_frames][height][row_stride];
+ * d_flow float32 [n_frames-1][height][width][2], flow i = (frame i -> frame i+1), exactly what n_frames-1 calls
+ * of nsof_farneback_u8 on consecutive frames give (the reference's seg/ob/prediction loops walk a sequence this
+ * way, optical_flow_seg.py:413-496).  Each frame's pyramid levels and polynomial expansion are computed once and
+ * shared by the two pairs the frame belongs to.  Asynchronous on the context's stream. */
+int nsof_farneback_u8_sequence_dev(nsof_ctx* ctx, int n_frames, const uint8_t* d_frames,
+                                   ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                   int width, int height, float* d_flow,
+                                   double pyr_scale, int levels, int winsize, int iterations,
+                                   int poly_n, double poly_sigma, int flags);
+
 /* Geometry helpers (pure host arithmetic, usable without a device: ctx may be NULL). */
 int nsof_farneback_effective_levels(int width, int height, double pyr_scale, int levels);
 int nsof_farneback_level_size(int width, int height, double pyr_scale, int level,

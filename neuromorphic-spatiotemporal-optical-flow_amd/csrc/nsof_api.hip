@@ -391,12 +391,16 @@ extern "C" int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float*
 // ---- the Farneback driver --------------------------------------------------------------------
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
-                                           ptrdiff_t row_stride, ptrdiff_t pair_stride, int width, int height,
-                                           float* d_flow, double pyr_scale, int levels, int winsize, int iterations,
-                                           int poly_n, double poly_sigma, int flags)
+// Core of both device entry points.  sequence == false: n_pairs independent pairs (d_prev[i], d_next[i]);
+// sequence == true: n_pairs + 1 consecutive frames in d_prev (d_next unused), pair i = (frame i, frame i+1) -- every
+// frame's pyramid level and polynomial expansion is then computed once and shared by the two pairs it belongs to.
+static int farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
+                          ptrdiff_t row_stride, ptrdiff_t pair_stride, int width, int height, float* d_flow,
+                          double pyr_scale, int levels, int winsize, int iterations, int poly_n, double poly_sigma,
+                          int flags)
 {
     if (!ctx) return NSOF_EINVAL;
+    if (sequence) d_next = d_prev;
     if (!d_prev || !d_next || !d_flow || n_pairs < 1) return nsof_set_error(ctx, NSOF_EINVAL, "null buffer or n_pairs<1");
     if (n_pairs > 32767)   // 2*n_pairs images go on gridDim.z
         return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "n_pairs=%d exceeds 32767 per call", n_pairs);
@@ -412,10 +416,11 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
     // workspace: I [2][B][n0] f32, R [2][B][5][n0] f32, S = second flow buffer [B][n0][2]
     // (+ M [B][5][n0] only when the window is too large for the fused iteration kernel)
     const size_t n0 = (size_t)width * height, B = (size_t)n_pairs;
+    const size_t n_img = sequence ? B + 1 : 2 * B;   // frames of a sequence, or B prev + B next frames
     // decided once for the whole pyramid (the coarsest level is never smaller than 2x2 when min_size is 32;
     // tiny inputs whose level 0 is below 2x2 take the unfused pair)
     const bool fused = nsof_iterate_supported(winsize, width, height);
-    const size_t szI = align_up(B * 2 * n0 * 4, 256), szR = align_up(B * 10 * n0 * 4, 256);
+    const size_t szI = align_up(n_img * n0 * 4, 256), szR = align_up(n_img * 5 * n0 * 4, 256);
     const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
     if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM))) return rc;
     char* base = (char*)ctx->ws;
@@ -459,15 +464,20 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
                 return rc;
             cur ^= 1;
         }
-        // image-major batches: dI [2][B][hk][wk] (all prev frames, then all next frames),
-        // dR [2][B][5][hk][wk]; one prep launch per frame set, one polyexp launch for all 2B images.
-        for (int i = 0; i < 2; i++)
-            if ((rc = nsof_launch_prep(ctx, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width, height,
-                                       wk, hk, btaps, dI + (size_t)i * B * nk)))
+        // image-major: dI [n_img][hk][wk], dR [n_img][5*hk*wk].  Pairs: all prev frames then all next frames
+        // (R1 = R0 + B images); sequence: the frames in order (R1 = R0 + 1 image).
+        if (sequence) {
+            if ((rc = nsof_launch_prep(ctx, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, btaps, dI)))
                 return rc;
-        if ((rc = nsof_launch_polyexp(ctx, 2 * n_pairs, dI, wk, hk, ptaps, dR))) return rc;
+        } else {
+            for (int i = 0; i < 2; i++)
+                if ((rc = nsof_launch_prep(ctx, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width,
+                                           height, wk, hk, btaps, dI + (size_t)i * B * nk)))
+                    return rc;
+        }
+        if ((rc = nsof_launch_polyexp(ctx, (int)n_img, dI, wk, hk, ptaps, dR))) return rc;
         const float* R0 = dR;
-        const float* R1 = dR + B * 5 * nk;
+        const float* R1 = dR + (sequence ? (size_t)1 : B) * 5 * nk;
         if (fused) {
             for (int it = 0; it < iterations; it++) {
                 if (it == 0 && pending_ups)
@@ -494,6 +504,26 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
     if (fb[cur] != d_flow)  // cannot happen by construction; keep the result correct regardless
         NSOF_HIP(ctx, hipMemcpyAsync(d_flow, fb[cur], B * n0 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return NSOF_OK;
+}
+
+extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
+                                           ptrdiff_t row_stride, ptrdiff_t pair_stride, int width, int height,
+                                           float* d_flow, double pyr_scale, int levels, int winsize, int iterations,
+                                           int poly_n, double poly_sigma, int flags)
+{
+    return farneback_core(ctx, false, n_pairs, d_prev, d_next, row_stride, pair_stride, width, height, d_flow, pyr_scale,
+                          levels, winsize, iterations, poly_n, poly_sigma, flags);
+}
+
+extern "C" int nsof_farneback_u8_sequence_dev(nsof_ctx* ctx, int n_frames, const uint8_t* d_frames,
+                                              ptrdiff_t row_stride, ptrdiff_t frame_stride, int width, int height,
+                                              float* d_flow, double pyr_scale, int levels, int winsize,
+                                              int iterations, int poly_n, double poly_sigma, int flags)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (n_frames < 2) return nsof_set_error(ctx, NSOF_EINVAL, "a sequence needs at least 2 frames");
+    return farneback_core(ctx, true, n_frames - 1, d_frames, nullptr, row_stride, frame_stride, width, height, d_flow,
+                          pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags);
 }
 
 extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t prev_stride, const uint8_t* next,

@@ -14,7 +14,7 @@ All arithmetic runs in libnsof.so (HIP, gfx950).  No fallbacks.
 """
 from .errors import NsofError, error  # noqa: F401
 from .context import Context, default_context  # noqa: F401
-from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_levels, farneback_batch,  # noqa: F401
+from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_levels, farneback_batch, farneback_sequence,  # noqa: F401
                         install, level_size, uninstall)
 from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, load_events, resistance_exp,  # noqa: F401
                           simulate, simulate_frames, slice_indices, update_state)

@@ -25,6 +25,7 @@ SIGNATURES = {
     "nsof_synchronize": (_i, [_vp]),
     "nsof_farneback_u8": (_i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp, _pd, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_batch_dev": (_i, [_vp, _i, _vp, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
+    "nsof_farneback_u8_sequence_dev": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_effective_levels": (_i, [_i, _i, _d, _i]),
     "nsof_farneback_level_size": (_i, [_i, _i, _d, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_d)]),
     "nsof_stage_pyr_level": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _d, _i, _vp]),

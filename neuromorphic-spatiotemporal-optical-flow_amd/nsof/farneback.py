@@ -88,6 +88,21 @@ def farneback_batch(d_prev, d_next, d_flow, n_pairs, height, width, params, *, r
     ctx.check(rc, "farneback_batch")
 
 
+def farneback_sequence(d_frames, d_flow, n_frames, height, width, params, *, row_stride=None, frame_stride=None,
+                       ctx=None):
+    """Device-resident sequence: ``d_frames`` uint8 [n_frames][H][row_stride]; ``d_flow`` float32
+    [n_frames-1][H][W][2] with flow i = frame i -> frame i+1 (the consecutive-pair walk of the reference's scripts).
+    Per-frame work (pyramid, polynomial expansion) is shared between neighbouring pairs."""
+    ctx = ctx or default_context()
+    row_stride = width if row_stride is None else row_stride
+    frame_stride = row_stride * height if frame_stride is None else frame_stride
+    p = params
+    rc = ctx._lib.nsof_farneback_u8_sequence_dev(ctx.ptr, n_frames, dev_ptr(d_frames), row_stride, frame_stride,
+                                                 width, height, dev_ptr(d_flow), p.pyr_scale, p.levels, p.winsize,
+                                                 p.iterations, p.poly_n, p.poly_sigma, p.flags)
+    ctx.check(rc, "farneback_sequence")
+
+
 def effective_levels(width, height, pyr_scale, levels):
     return _lib.load().nsof_farneback_effective_levels(width, height, pyr_scale, levels)
 

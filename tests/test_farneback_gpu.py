@@ -330,3 +330,21 @@ def test_fuzz_parameters_vs_oracle(nsof_lib, ctx, oracle):
         worst = max(worst, err)
         assert err <= PIPE_TOL * max(1.0, float(np.abs(want).max()) / 10), (case, (h, w), p, err)
     assert worst <= 1e-4
+
+
+def test_sequence_equals_consecutive_pairs(nsof_lib, ctx, torch_dev):
+    """nsof_farneback_u8_sequence_dev == one call per consecutive pair, bit for bit (params A and B)."""
+    import torch
+    from nsof import synth
+    h, w, n = 120, 200, 6
+    base, _ = synth.make_pair(9, h + 40, w + 40)
+    frames = np.stack([np.ascontiguousarray(base[10 + 2 * i:10 + 2 * i + h, 5 + 3 * i:5 + 3 * i + w]) for i in range(n)])
+    d = _dev(torch_dev, frames)
+    for params in (A, B):
+        out = torch.empty((n - 1, h, w, 2), dtype=torch.float32, device=torch_dev)
+        nsof_lib.farneback_sequence(d, out, n, h, w, nsof_lib.FarnebackParams(*params), ctx=ctx)
+        ctx.synchronize()
+        got = out.cpu().numpy()
+        for i in range(n - 1):
+            one = nsof_lib.calcOpticalFlowFarneback(frames[i], frames[i + 1], None, *params, ctx=ctx)
+            assert np.array_equal(got[i], one), (params, i)
