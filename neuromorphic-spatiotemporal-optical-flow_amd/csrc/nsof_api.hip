@@ -139,6 +139,7 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->tmp) hipFree(ctx->tmp);
+    if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -419,7 +420,9 @@ static int farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8
     const size_t n_img = sequence ? B + 1 : 2 * B;   // frames of a sequence, or B prev + B next frames
     // decided once for the whole pyramid (the coarsest level is never smaller than 2x2 when min_size is 32;
     // tiny inputs whose level 0 is below 2x2 take the unfused pair)
-    const bool fused = nsof_iterate_supported(winsize, width, height);
+    // NSOF_FUSED=0 forces the unfused pair (A/B runs; measured slower even for a lone 1080p pair: 6.1 vs 4.0 ms).
+    static const char* fused_env = getenv("NSOF_FUSED");
+    const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0');
     const size_t szI = align_up(n_img * n0 * 4, 256), szR = align_up(n_img * 5 * n0 * 4, 256);
     const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
     if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM))) return rc;
@@ -537,19 +540,48 @@ extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t p
     if (rc) return rc;
     if (flow_stride < (ptrdiff_t)(width * 8)) return nsof_set_error(ctx, NSOF_EINVAL, "flow_stride < width*8");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t pitch = align_up((size_t)width, 64), n0 = (size_t)width * height;
-    const size_t szU = align_up(pitch * height, 256), szF = align_up(n0 * 8, 256);
+    // Strided host views are packed row by row into a pinned staging buffer and moved with ONE linear copy per
+    // direction: hipMemcpy2D degenerates to a copy per row for widths that are not nicely aligned (measured 12 ms
+    // for an 801x801 pair against 3 ms of kernels).
+    const size_t n0 = (size_t)width * height, pitch = (size_t)width;
+    const size_t szU = align_up(n0, 256), szF = align_up(n0 * 8, 256);
     if ((rc = nsof_ws_reserve(ctx, &ctx->stage, &ctx->stage_bytes, 2 * szU + szF))) return rc;
+    if (ctx->hstage_bytes < 2 * szU + szF) {
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->hstage) hipHostFree(ctx->hstage);
+        ctx->hstage = nullptr;
+        ctx->hstage_bytes = 0;
+        hipError_t e = hipHostMalloc(&ctx->hstage, 2 * szU + szF, hipHostMallocDefault);
+        if (e != hipSuccess)
+            return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu) failed: %s", 2 * szU + szF, hipGetErrorString(e));
+        ctx->hstage_bytes = 2 * szU + szF;
+    }
+    uint8_t* hP = (uint8_t*)ctx->hstage;
+    uint8_t* hN = hP + szU;
+    float* hF = (float*)(hN + szU);
     uint8_t* dP = (uint8_t*)ctx->stage;
     uint8_t* dN = dP + szU;
     float* dFl = (float*)(dN + szU);
-    NSOF_HIP(ctx, hipMemcpy2DAsync(dP, pitch, prev, prev_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
-    NSOF_HIP(ctx, hipMemcpy2DAsync(dN, pitch, next, next_stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    const bool in_dense = prev_stride == (ptrdiff_t)width && next_stride == (ptrdiff_t)width;
+    const bool out_dense = flow_stride == (ptrdiff_t)width * 8;
+    if (in_dense) {   // contiguous frames: straight from the caller's memory
+        NSOF_HIP(ctx, hipMemcpyAsync(dP, prev, n0, hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipMemcpyAsync(dN, next, n0, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        for (int y = 0; y < height; y++) {
+            memcpy(hP + (size_t)y * width, prev + (ptrdiff_t)y * prev_stride, (size_t)width);
+            memcpy(hN + (size_t)y * width, next + (ptrdiff_t)y * next_stride, (size_t)width);
+        }
+        NSOF_HIP(ctx, hipMemcpyAsync(dP, hP, 2 * szU, hipMemcpyHostToDevice, ctx->stream));
+    }
     rc = nsof_farneback_u8_batch_dev(ctx, 1, dP, dN, (ptrdiff_t)pitch, (ptrdiff_t)szU, width, height, dFl, pyr_scale,
                                      levels, winsize, iterations, poly_n, poly_sigma, flags);
     if (rc) return rc;
-    NSOF_HIP(ctx, hipMemcpy2DAsync(flow, flow_stride, dFl, (size_t)width * 8, (size_t)width * 8, height,
-                                   hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipMemcpyAsync(out_dense ? flow : hF, dFl, n0 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!out_dense)
+        for (int y = 0; y < height; y++)
+            memcpy((char*)flow + (ptrdiff_t)y * flow_stride, hF + (size_t)y * width * 2, (size_t)width * 8);
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NSOF_OK;
 }

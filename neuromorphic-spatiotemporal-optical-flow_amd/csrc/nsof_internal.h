@@ -31,6 +31,9 @@ struct nsof_ctx {
     // staging for the host-pointer entry point
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    // pinned host staging of the host-pointer entry point (frames in, flow out)
+    void* hstage = nullptr;
+    size_t hstage_bytes = 0;
     // row-filtered intermediate of the two-pass pyramid kernels
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
