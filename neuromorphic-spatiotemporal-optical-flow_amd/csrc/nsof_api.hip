@@ -414,12 +414,11 @@ static int farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8
     if ((rc = nsof_host_poly_taps(poly_n, poly_sigma, &ptaps))) return nsof_set_error(ctx, rc, "poly taps");
     const int L = nsof_farneback_effective_levels(width, height, pyr_scale, levels);
 
-    // workspace: I [2][B][n0] f32, R [2][B][5][n0] f32, S = second flow buffer [B][n0][2]
+    // workspace: I [n_img][n0] f32, R [n_img][5*n0] f32, S = second flow buffer [B][n0][2]
     // (+ M [B][5][n0] only when the window is too large for the fused iteration kernel)
     const size_t n0 = (size_t)width * height, B = (size_t)n_pairs;
     const size_t n_img = sequence ? B + 1 : 2 * B;   // frames of a sequence, or B prev + B next frames
-    // decided once for the whole pyramid (the coarsest level is never smaller than 2x2 when min_size is 32;
-    // tiny inputs whose level 0 is below 2x2 take the unfused pair)
+    // Fused or unfused is decided once for the whole pyramid (inputs below 2x2 take the unfused pair).
     // NSOF_FUSED=0 forces the unfused pair (A/B runs; measured slower even for a lone 1080p pair: 6.1 vs 4.0 ms).
     static const char* fused_env = getenv("NSOF_FUSED");
     const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0');
