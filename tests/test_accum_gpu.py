@@ -132,3 +132,34 @@ def test_frame_driven_variant_vs_oracle(nsof_lib, ctx, oracle):
         assert (np.abs(res - rr) / rr).max() < 1e-9
     w2, _ = nsof_lib.simulate_frames(imgs, th1=2.0, n_sub_steps=10, ctx=ctx)   # vehicle variant, fast simulation
     assert np.abs(w2 - oracle.accum_frames(imgs, n_sub=10, th1=2.0)[0]).max() < 1e-12
+
+
+def test_output_files_match_reference_format(nsof_lib, ctx, tmp_path):
+    """simulate(out_prefix=...) writes the reference's file set (event_mem_sim.py:289-322): .V{v}.npz with
+    w_final/resistances (float32), .V2_b.npz (empty arrays in magnitude mode), .V{v}.json.gz metadata."""
+    import gzip
+    import json
+    d = np.load(golden_path("accum_sim_v2_split.npz"))
+    H, W = d["w_final"].shape
+    ev = (d["x"], d["y"], d["p"], d["t"])
+    prefix = tmp_path / "stream.hdf5"
+    out = nsof_lib.simulate(ev, version=2, slice_us=1000, active_v=-6.0, silent_v=0.0, polarity="split",
+                            sensor_size=(H, W), out_prefix=prefix, ctx=ctx)
+    a = np.load(tmp_path / "stream.V2.npz")
+    b = np.load(tmp_path / "stream.V2_b.npz")
+    assert sorted(a.files) == ["resistances", "w_final"] and a["resistances"].dtype == np.float32
+    assert np.array_equal(a["w_final"], out["w_final"]) and np.array_equal(b["w_final"], out["w_final_b"])
+    with gzip.open(tmp_path / "stream.V2.json.gz", "rt") as f:
+        meta = json.load(f)
+    assert set(meta) == {"version", "slice_us", "fps", "params", "dt", "scheme", "polarity", "theta_events",
+                         "refractory_us", "event_file"}
+    assert meta["scheme"] == "dc_bias_overlay" and meta["refractory_us"] == 800 and meta["theta_events"] is None
+    assert meta["params"]["koff"] == 51.03 and meta["dt"] == 5e-4 and meta["fps"] == 1000.0
+    nsof_lib.simulate(ev, version=2, polarity="magnitude", active_v=-6.0, sensor_size=(H, W),
+                      out_prefix=tmp_path / "m.hdf5", ctx=ctx)
+    assert np.load(tmp_path / "m.V2_b.npz")["w_final"].size == 0
+    nsof_lib.simulate(ev, version=1, active_v=-6.0, sensor_size=(H, W), out_prefix=tmp_path / "one.hdf5", ctx=ctx)
+    with gzip.open(tmp_path / "one.V1.json.gz", "rt") as f:
+        m1 = json.load(f)
+    assert m1["scheme"] == "boxcar" and m1["polarity"] is None and m1["theta_events"] == 1
+    assert not (tmp_path / "one.V2_b.npz").exists()
