@@ -379,6 +379,9 @@ __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Pla
 {
     RowIn in[4];
     typename FS::Raw fl[4];
+#ifdef NSOF_PRODUCER_PRIO
+    __builtin_amdgcn_s_setprio(NSOF_PRODUCER_PRIO);   // experiment: issue the gather ahead of the consumers' arithmetic
+#endif
     auto flowAt = [&](int r) { return F.at(r); };
 #pragma unroll
     for (int j = 0; j < 4; j++) {   // steps 0..3 in flight
@@ -417,6 +420,9 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
     using G = PCGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
     double vs[5];
+#ifdef NSOF_CONSUMER_PRIO
+    __builtin_amdgcn_s_setprio(NSOF_CONSUMER_PRIO);   // experiment: the consumers' dependent chain first
+#endif
     auto flowAt = [&](int r) { return F.at(r); };
     {
         // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
