@@ -127,3 +127,27 @@ def test_roi_flow_equals_standalone_crop(nsof_lib, ctx, maps):
     outside = flow.copy()
     outside[y0:y1, x0:x1] = 0
     assert not outside.any()
+
+
+@pytest.mark.gpu
+def test_events_to_roi_to_flow_pipeline(nsof_lib, ctx):
+    """Config-3 style chain on a small sensor: a drifting box emits events, the accumulator's surface gates an ROI
+    around it, and the flow is computed only there."""
+    from nsof import gating, pipeline, synth
+    H, W = 240, 320
+    x, y, p, t = synth.make_events(7, W, H, n_background=0, duration_us=120_000, box=(40, 30), speed_pps=500.0)
+    cfg = gating.GatingConfig(MEMSIZE=20, EXTEND_HEIGHT_UPPER=10, EXTEND_HEIGHT_LOWER=10, EXTEND_WIDTH_LEFT=10,
+                              EXTEND_WIDTH_RIGHT=10, THRES=240, FLAG=2, farneback_params=nsof_lib.farneback.PARAMS_A)
+    # silent_v = 0.5 V > von: idle devices leak towards Roff (gray 226 < THRES) while event pixels are driven up
+    rois = pipeline.events_to_rois(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5, snapshot_every=40, ctx=ctx)
+    assert len(rois) == 3
+    g, rects = rois[-1]
+    assert g.shape == (H // 20, W // 20) and len(rects) >= 1
+    # the box travelled from x=40 to x=100 in rows 105..135: every ROI lies on that band
+    for (x0, y0, x1, y1) in rects:
+        assert y0 <= 105 and y1 >= 135 and x0 < 110 and x1 > 30 and (x1 - x0) < W
+    prev, nxt = synth.make_pair(3, H, W)
+    fl = lambda a, b, f, **kw: nsof_lib.calcOpticalFlowFarneback(a, b, f, **kw, ctx=ctx)  # noqa: E731
+    flow, _, _, _, rect = pipeline.gated_flow(g, prev, nxt, cfg, flow_fn=fl)
+    x0, y0, x1, y1 = rect
+    assert flow[y0:y1, x0:x1].any() and not flow[:max(y0 - 1, 0)].any()
