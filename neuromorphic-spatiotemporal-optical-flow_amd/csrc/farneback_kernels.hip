@@ -463,12 +463,15 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
     // The 2N double-precision taps would not fit the scalar register file next to the float taps (SGPR
     // spills cost more than the arithmetic); they live in LDS and are re-read (broadcast) once per step.
     __shared__ double stap[2][N + 1];
+    __shared__ float ftap[2][N + 1];   // g, xg for the horizontal pass when N is large (see HT below)
     __shared__ float4 st[4][256];   // per-wave transpose buffer for the interleaved channel-0..3 stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid <= N) {
         stap[0][tid] = tp.dg[tid];
         stap[1][tid] = tp.dxxg[tid];
+        ftap[0][tid] = tp.g[tid];
+        ftap[1][tid] = tp.xg[tid];
     }
     const int x0 = blockIdx.x * G::SW;
     const int ys = blockIdx.y * seg_rows, ye = min(ys + seg_rows, H);
@@ -535,6 +538,15 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
             };
             double t03[4];  // b1 * ig03, shared by the xx and yy outputs
             float o0[4], o1[4], o2[4], o3[4], o4[4];
+            // Large radii: 3(N+1) float + 2N double taps exceed the scalar register file (the spills cost more than
+            // the arithmetic), so the horizontal pass takes its float taps from LDS into VGPRs as well.
+            constexpr bool HT = N > 7;
+            float hg[N + 1], hxg[N + 1];
+#pragma unroll
+            for (int k = 0; k <= N; k++) {
+                hg[k] = HT ? ftap[0][k] : tp.g[k];
+                hxg[k] = HT ? ftap[1][k] : tp.xg[k];
+            }
             {
                 float v[4 * G::NV];
                 double dg[N + 1], dxxg[N + 1];
@@ -547,14 +559,14 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int c = G::NP + p;
-                    double a1 = (double)(v[c] * tp.g[0]), a2 = 0, a4 = 0;
+                    double a1 = (double)(v[c] * hg[0]), a2 = 0, a4 = 0;
 #pragma unroll
                     for (int k = 1; k <= N; k++) {
                         const float hi = v[c + k], lo = v[c - k];
                         const double tg = (double)(hi + lo);
                         a1 = fma(tg, dg[k], a1);     // product of two float-valued doubles is exact
                         a4 = fma(tg, dxxg[k], a4);
-                        a2 += (double)((hi - lo) * tp.xg[k]);
+                        a2 += (double)((hi - lo) * hxg[k]);
                     }
                     t03[p] = a1 * tp.ig03;
                     o1[p] = (float)(a2 * tp.ig11);
@@ -567,12 +579,12 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int c = G::NP + p;
-                    double a3 = (double)(v[c] * tp.g[0]), a6 = 0;
+                    double a3 = (double)(v[c] * hg[0]), a6 = 0;
 #pragma unroll
                     for (int k = 1; k <= N; k++) {
                         const float hi = v[c + k], lo = v[c - k];
-                        a3 += (double)((hi + lo) * tp.g[k]);
-                        a6 += (double)((hi - lo) * tp.xg[k]);
+                        a3 += (double)((hi + lo) * hg[k]);
+                        a6 += (double)((hi - lo) * hxg[k]);
                     }
                     o0[p] = (float)(a3 * tp.ig11);
                     o4[p] = (float)(a6 * tp.ig55);
@@ -584,9 +596,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int c = G::NP + p;
-                    double a5 = (double)(v[c] * tp.g[0]);
+                    double a5 = (double)(v[c] * hg[0]);
 #pragma unroll
-                    for (int k = 1; k <= N; k++) a5 += (double)((v[c + k] + v[c - k]) * tp.g[k]);
+                    for (int k = 1; k <= N; k++) a5 += (double)((v[c + k] + v[c - k]) * hg[k]);
                     o2[p] = (float)(t03[p] + a5 * tp.ig33);
                 }
             }
