@@ -19,8 +19,9 @@ from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_lev
 from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, load_events, resistance_exp,  # noqa: F401
                           simulate, simulate_frames, slice_indices, update_state)
 
-from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, gating_maps,  # noqa: F401,E402
-                     opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
+from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, frame_to_gray,  # noqa: F401,E402
+                     gating_maps, opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
+from .flowviz import flow_to_image, flow_uv_to_colors, make_colorwheel  # noqa: F401,E402
 
 __all__ = ["calcOpticalFlowFarneback", "install", "uninstall", "FarnebackParams", "farneback_batch", "Context",
            "default_context", "simulate", "update_state", "resistance_exp", "Accumulator", "NsofError", "error"]

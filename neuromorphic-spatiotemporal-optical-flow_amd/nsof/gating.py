@@ -66,6 +66,21 @@ def current_to_gray(mem_state):
     return np.clip(g, 0, 255).astype(np.uint8)
 
 
+def frame_to_gray(frame, code="RGB2GRAY"):
+    """8-bit luma of a 3-channel uint8 frame, as ``cv2.cvtColor(frame, cv2.COLOR_RGB2GRAY)`` computes it
+    (optical_flow_seg.py:442-443).  cv2's 8-bit path is fixed point: ``(R*9798 + G*19235 + B*3735 + 2^14) >> 15``.
+    The scripts apply RGB2GRAY to ``cv2.imread`` output, which is B,G,R ordered, so channel 0 (blue) gets the red
+    weight; ``code="BGR2GRAY"`` gives the conventional weighting (seg.py:447)."""
+    f = np.asarray(frame)
+    if f.ndim != 3 or f.shape[2] != 3 or f.dtype != np.uint8:
+        raise ValueError("frame must be uint8 [H,W,3]")
+    wts = {"RGB2GRAY": (9798, 19235, 3735), "BGR2GRAY": (3735, 19235, 9798)}[code]
+    acc = np.full(f.shape[:2], 1 << 14, np.int32)
+    for c in range(3):
+        acc += f[..., c].astype(np.int32) * wts[c]
+    return (acc >> 15).astype(np.uint8)
+
+
 def gating_maps(mem_state, i, cfg):
     """(memimg1, memimg2) for frame pair i from the ``constructed3DMatrix`` stack (seg.py:416-437).
     With ``cfg.bug_compatible`` memimg2 is a copy of memimg1, as in the shipped scripts."""
