@@ -128,7 +128,9 @@ typedef enum nsof_kernel_id {
     NSOF_K_BLUR = 4,        /* box blur + 2x2 solve */
     NSOF_K_ACCUM = 5,       /* accumulator state update */
     NSOF_K_ITERATE = 6,     /* fused matrix update + box blur + solve (one Farneback iteration) */
-    NSOF_K_COUNT = 7
+    NSOF_K_SEGMENT = 7,     /* |flow| > th (or u8 != 0) -> bit-packed mask */
+    NSOF_K_MORPH = 8,       /* fused dilate/erode chain on the bit-packed mask */
+    NSOF_K_COUNT = 9
 } nsof_kernel_id;
 /* mask: bit (1<<id) enables event bracketing for that kernel; 0 disables. */
 int nsof_prof_enable(nsof_ctx* ctx, unsigned mask);
@@ -178,6 +180,36 @@ int nsof_accum_frames_f64(nsof_ctx* ctx, const double* imgs, int n_frames, int h
 /* slice_indices() of event_mem_sim.py:78-83 on a HOST timestamp array: returns the number
  * of bounds and fills idx (if not NULL) with up to cap entries. */
 int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t slice_us, int64_t* idx, int64_t cap);
+
+/* ---- next: motion-segmentation head on the flow field --------------------- */
+/* Replaces, in /root/reference/optical_flow_seg.py, the chain
+ *   mag, ang = cv2.cartToPolar(flow_x, flow_y)                         :283, :503
+ *   motion_mask[mag > SEG_TH] = 255                                     :346-347
+ *   kernel = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (10, 10))     :350
+ *   5 x { cv2.dilate(mask, kernel); cv2.erode(mask, kernel) }           :351-353
+ *   cv2.threshold(mask, 1, 255, cv2.THRESH_BINARY)                      :356
+ * (process_flow_region :322-357; baseline copy :503-537).  Both operations take
+ * dst(x,y) = max|min over element(i,j) != 0 of src(x + j - ax, y + i - ay), anchor = ksize/2,
+ * pixels outside the image do not take part (cv2's default morphology border). */
+enum { NSOF_MORPH_RECT = 0, NSOF_MORPH_CROSS = 1, NSOF_MORPH_ELLIPSE = 2 };   /* cv2.MORPH_RECT/CROSS/ELLIPSE */
+enum { NSOF_MORPH_ERODE = 0, NSOF_MORPH_DILATE = 1 };
+/* cv2.getStructuringElement(shape, (kw, kh)) -> out[kh][kw] of 0/1 (HOST). */
+int nsof_structuring_element(int shape, int kw, int kh, uint8_t* out);
+/* cv2.dilate / cv2.erode for two-valued masks on DEVICE memory: non-zero source pixels count as set, the
+ * result is 0/255.  elem = HOST [kh][kw] (non-zero = member), up to 32x32 with at most 8 distinct rows;
+ * anchor (-1,-1) = centre; `iterations` repeats the operation.  strides in bytes. */
+int nsof_morph_binary_u8_dev(nsof_ctx* ctx, int op, const uint8_t* d_src, ptrdiff_t src_stride, int width,
+                             int height, const uint8_t* elem, int kw, int kh, int anchor_x, int anchor_y,
+                             int iterations, uint8_t* d_dst, ptrdiff_t dst_stride);
+/* The whole head on a DEVICE flow field [h][w][2] float32 (row stride in floats, even): mask = 255 where
+ * sqrt(u^2 + v^2) (in double, as cartToPolar sees the float64 canvas) > thresh, then `iterations` x
+ * (dilate, erode) with the ksize x ksize ellipse, all in one pass over the flow plus one fused launch on the
+ * bit-packed mask.  d_mask [h][mask_stride] uint8. */
+int nsof_motion_mask_dev(nsof_ctx* ctx, const float* d_flow, ptrdiff_t flow_stride_floats, int width, int height,
+                         double thresh, int ksize, int iterations, uint8_t* d_mask, ptrdiff_t mask_stride);
+/* Same with HOST pointers (flow row stride in bytes: ROI views of the flow canvas are passed as they are). */
+int nsof_motion_mask(nsof_ctx* ctx, const float* flow, ptrdiff_t flow_stride_bytes, int width, int height,
+                     double thresh, int ksize, int iterations, uint8_t* mask, ptrdiff_t mask_stride);
 
 #ifdef __cplusplus
 }

@@ -86,10 +86,23 @@ extern "C" int nsof_prof_collect(nsof_ctx* ctx, int id, double* total_ms, long l
     return NSOF_OK;
 }
 
+int nsof_hstage_reserve(nsof_ctx* ctx, size_t need)
+{
+    if (ctx->hstage_bytes >= need) return NSOF_OK;
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->hstage) hipHostFree(ctx->hstage);
+    ctx->hstage = nullptr;
+    ctx->hstage_bytes = 0;
+    hipError_t e = hipHostMalloc(&ctx->hstage, need, hipHostMallocDefault);
+    if (e != hipSuccess) return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    ctx->hstage_bytes = need;
+    return NSOF_OK;
+}
+
 extern "C" const char* nsof_kernel_name(int id)
 {
     static const char* names[NSOF_K_COUNT] = {"prep", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
-                                              "accum_update", "iterate"};
+                                              "accum_update", "iterate", "mask_pack", "morph_chain"};
     return (id >= 0 && id < NSOF_K_COUNT) ? names[id] : "?";
 }
 
@@ -545,16 +558,7 @@ extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t p
     const size_t n0 = (size_t)width * height, pitch = (size_t)width;
     const size_t szU = align_up(n0, 256), szF = align_up(n0 * 8, 256);
     if ((rc = nsof_ws_reserve(ctx, &ctx->stage, &ctx->stage_bytes, 2 * szU + szF))) return rc;
-    if (ctx->hstage_bytes < 2 * szU + szF) {
-        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->hstage) hipHostFree(ctx->hstage);
-        ctx->hstage = nullptr;
-        ctx->hstage_bytes = 0;
-        hipError_t e = hipHostMalloc(&ctx->hstage, 2 * szU + szF, hipHostMallocDefault);
-        if (e != hipSuccess)
-            return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu) failed: %s", 2 * szU + szF, hipGetErrorString(e));
-        ctx->hstage_bytes = 2 * szU + szF;
-    }
+    if ((rc = nsof_hstage_reserve(ctx, 2 * szU + szF))) return rc;
     uint8_t* hP = (uint8_t*)ctx->hstage;
     uint8_t* hN = hP + szU;
     float* hF = (float*)(hN + szU);

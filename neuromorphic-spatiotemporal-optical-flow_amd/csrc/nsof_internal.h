@@ -41,6 +41,8 @@ struct nsof_ctx {
 
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
 int nsof_ws_reserve(nsof_ctx* ctx, void** buf, size_t* cur, size_t need);
+// Grow ctx->hstage (pinned host staging) to at least `need` bytes.
+int nsof_hstage_reserve(nsof_ctx* ctx, size_t need);
 
 #define NSOF_HIP(ctx, call)                                                                      \
     do {                                                                                         \

@@ -21,6 +21,8 @@ from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, 
 
 from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, frame_to_gray,  # noqa: F401,E402
                      gating_maps, opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
+from .segment import (MORPH_CROSS, MORPH_ELLIPSE, MORPH_RECT, dilate, erode, getStructuringElement, motion_mask,  # noqa: F401,E402
+                      motion_mask_dev, process_flow_region, task_results)
 from .flowviz import flow_to_image, flow_uv_to_colors, make_colorwheel  # noqa: F401,E402
 
 __all__ = ["calcOpticalFlowFarneback", "install", "uninstall", "FarnebackParams", "farneback_batch", "Context",

@@ -233,3 +233,42 @@ def accum_simulate(x, y, p, t, H, W, version, polarity, slice_us, active_v, sile
     if split:
         out.update(w_final_b=wb, resistances_b=rb)
     return out
+
+
+# ---------------------------------------------------------------- segmentation head
+def structuring_element(shape, kw, kh):
+    """shape 0 rect / 1 cross / 2 ellipse, as cv2.getStructuringElement(shape, (kw, kh))."""
+    out = np.empty((kh, kw), np.uint8)
+    l = lib()
+    l.nsof_ref_structuring_element.restype = C.c_int
+    l.nsof_ref_structuring_element.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _chk(l.nsof_ref_structuring_element(shape, kw, kh, out.ctypes.data), "structuring_element")
+    return out
+
+
+def morph(op, src, elem, anchor=(-1, -1)):
+    """op 0 erode / 1 dilate on a uint8 image (cv2 semantics: un-reflected element, outside ignored)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    elem = np.ascontiguousarray(elem, np.uint8)
+    h, w = src.shape
+    out = np.empty_like(src)
+    l = lib()
+    l.nsof_ref_morph_u8.restype = C.c_int
+    l.nsof_ref_morph_u8.argtypes = [C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
+    _chk(l.nsof_ref_morph_u8(op, src.ctypes.data, w, w, h, elem.ctypes.data, elem.shape[1], elem.shape[0],
+                             anchor[0], anchor[1], out.ctypes.data, w), "morph")
+    return out
+
+
+def motion_mask(flow, thresh=1.0, ksize=10, iters=5):
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w = flow.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    l = lib()
+    l.nsof_ref_motion_mask.restype = C.c_int
+    l.nsof_ref_motion_mask.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_ssize_t]
+    _chk(l.nsof_ref_motion_mask(flow.ctypes.data, 2 * w, w, h, thresh, ksize, iters, out.ctypes.data, w),
+         "motion_mask")
+    return out
