@@ -130,7 +130,9 @@ typedef enum nsof_kernel_id {
     NSOF_K_ITERATE = 6,     /* fused matrix update + box blur + solve (one Farneback iteration) */
     NSOF_K_SEGMENT = 7,     /* |flow| > th (or u8 != 0) -> bit-packed mask */
     NSOF_K_MORPH = 8,       /* fused dilate/erode chain on the bit-packed mask */
-    NSOF_K_COUNT = 9
+    NSOF_K_REMAP = 9,       /* 8-bit bilinear remap / fused prediction warp */
+    NSOF_K_SSIM = 10,       /* SSIM window statistics + per-block partial sums */
+    NSOF_K_COUNT = 11
 } nsof_kernel_id;
 /* mask: bit (1<<id) enables event bracketing for that kernel; 0 disables. */
 int nsof_prof_enable(nsof_ctx* ctx, unsigned mask);
@@ -210,6 +212,43 @@ int nsof_motion_mask_dev(nsof_ctx* ctx, const float* d_flow, ptrdiff_t flow_stri
 /* Same with HOST pointers (flow row stride in bytes: ROI views of the flow canvas are passed as they are). */
 int nsof_motion_mask(nsof_ctx* ctx, const float* flow, ptrdiff_t flow_stride_bytes, int width, int height,
                      double thresh, int ksize, int iterations, uint8_t* mask, ptrdiff_t mask_stride);
+
+/* ---- next: frame prediction by flow warp + SSIM --------------------------- */
+/* Replaces, in /root/reference/optical_flow_prediction.py,
+ *   flow_map = (grid + flow).astype(np.float32)                                         :289-290, :338-339, :581-582
+ *   cv2.remap(next_frame[:,:,c], flow_map[...,0], flow_map[...,1], cv2.INTER_LINEAR,
+ *             borderMode=cv2.BORDER_REPLICATE)      (gated path)                        :293-300, :342-349
+ *   cv2.remap(next_frame[:,:,c], map_x, map_y, cv2.INTER_LINEAR)   (baseline, constant 0) :584-586
+ *   structural_similarity(true[:,:,2], prediction[:,:,2], data_range=255.0)             :113-115
+ * remap follows cv2's 8-bit fixed point: map rounded to 1/32 px (half to even), integer part saturated to int16,
+ * 15-bit weights, (sum + 2^14) >> 15. */
+enum { NSOF_BORDER_CONSTANT = 0, NSOF_BORDER_REPLICATE = 1 };   /* cv2.BORDER_CONSTANT / cv2.BORDER_REPLICATE */
+/* cv2.remap for uint8 sources with 1 or 3 interleaved channels and two float32 maps, all on the DEVICE.
+ * Strides of the images in bytes, of the maps in floats.  Source up to 32767 x 32767. */
+int nsof_remap_linear_u8_dev(nsof_ctx* ctx, const uint8_t* d_src, ptrdiff_t src_stride, int src_w, int src_h,
+                             int channels, const float* d_map_x, ptrdiff_t map_x_stride_floats,
+                             const float* d_map_y, ptrdiff_t map_y_stride_floats, int dst_w, int dst_h,
+                             int border_mode, int border_value, uint8_t* d_dst, ptrdiff_t dst_stride);
+/* The prediction step for the region [y0,y1) x [x0,x1) of a frame, fused: map = float32(float64(grid) + sign *
+ * float64(flow)) is formed in the kernel from the DEVICE flow canvas [height][flow_stride_floats] (u,v) and the
+ * region of d_out (a frame-sized image; the caller pre-fills it with the frame, prediction.py:263) is overwritten
+ * with the warped d_frame.  sign = -1 for Farneback flow (prediction.py:545). */
+int nsof_predict_warp_u8_dev(nsof_ctx* ctx, const uint8_t* d_frame, ptrdiff_t frame_stride, int width, int height,
+                             int channels, const float* d_flow, ptrdiff_t flow_stride_floats, int sign,
+                             int x0, int y0, int x1, int y1, int border_mode, uint8_t* d_out, ptrdiff_t out_stride);
+/* Same with HOST pointers; flow_crop points at the region's first flow vector (row stride in bytes), i.e. the view
+ * flow[y0:y1, x0:x1] of a float32 canvas.  Only the region of `out` is written. */
+int nsof_predict_warp_u8(nsof_ctx* ctx, const uint8_t* frame, ptrdiff_t frame_stride, int width, int height,
+                         int channels, const float* flow_crop, ptrdiff_t flow_stride_bytes, int sign,
+                         int x0, int y0, int x1, int y1, int border_mode, uint8_t* out, ptrdiff_t out_stride);
+/* skimage.metrics.structural_similarity(a, b, data_range=...) with its defaults (7x7 uniform window, sample
+ * covariance, K1 0.01, K2 0.03) for 8-bit images on the DEVICE; pixel_step selects one channel of an interleaved
+ * image (3 for true[:,:,2] with the pointer advanced by 2).  *ssim_out is a HOST double; synchronises. */
+int nsof_ssim_u8_dev(nsof_ctx* ctx, const uint8_t* d_a, ptrdiff_t a_stride, int a_pixel_step, const uint8_t* d_b,
+                     ptrdiff_t b_stride, int b_pixel_step, int width, int height, double data_range,
+                     double* ssim_out);
+int nsof_ssim_u8(nsof_ctx* ctx, const uint8_t* a, ptrdiff_t a_stride, int a_pixel_step, const uint8_t* b,
+                 ptrdiff_t b_stride, int b_pixel_step, int width, int height, double data_range, double* ssim_out);
 
 #ifdef __cplusplus
 }

@@ -102,7 +102,7 @@ int nsof_hstage_reserve(nsof_ctx* ctx, size_t need)
 extern "C" const char* nsof_kernel_name(int id)
 {
     static const char* names[NSOF_K_COUNT] = {"prep", "polyexp", "flow_upsample", "update_matrices", "blur_solve",
-                                              "accum_update", "iterate", "mask_pack", "morph_chain"};
+                                              "accum_update", "iterate", "mask_pack", "morph_chain", "remap", "ssim"};
     return (id >= 0 && id < NSOF_K_COUNT) ? names[id] : "?";
 }
 

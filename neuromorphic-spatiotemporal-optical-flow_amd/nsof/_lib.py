@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnsof.so")
 
 NSOF_OK, NSOF_EINVAL, NSOF_ESHAPE, NSOF_EDEVICE, NSOF_ENOMEM, NSOF_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_SEGMENT, K_MORPH, K_COUNT = range(10)
+K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_SEGMENT, K_MORPH, K_REMAP, K_SSIM, K_COUNT = range(12)
 
 _vp, _i, _d, _f, _sz, _pd, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t, C.c_ssize_t, C.c_int64
 
@@ -55,6 +55,11 @@ SIGNATURES = {
     "nsof_morph_binary_u8_dev": (_i, [_vp, _i, _vp, _pd, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _pd]),
     "nsof_motion_mask_dev": (_i, [_vp, _vp, _pd, _i, _i, _d, _i, _i, _vp, _pd]),
     "nsof_motion_mask": (_i, [_vp, _vp, _pd, _i, _i, _d, _i, _i, _vp, _pd]),
+    "nsof_remap_linear_u8_dev": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd, _vp, _pd, _i, _i, _i, _i, _vp, _pd]),
+    "nsof_predict_warp_u8_dev": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd, _i, _i, _i, _i, _i, _i, _vp, _pd]),
+    "nsof_predict_warp_u8": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd, _i, _i, _i, _i, _i, _i, _vp, _pd]),
+    "nsof_ssim_u8_dev": (_i, [_vp, _vp, _pd, _i, _vp, _pd, _i, _i, _i, _d, C.POINTER(_d)]),
+    "nsof_ssim_u8": (_i, [_vp, _vp, _pd, _i, _vp, _pd, _i, _i, _i, _d, C.POINTER(_d)]),
 }
 
 _lib = None

@@ -272,3 +272,51 @@ def motion_mask(flow, thresh=1.0, ksize=10, iters=5):
     _chk(l.nsof_ref_motion_mask(flow.ctypes.data, 2 * w, w, h, thresh, ksize, iters, out.ctypes.data, w),
          "motion_mask")
     return out
+
+
+# ---------------------------------------------------------------- prediction warp + SSIM
+def remap_linear(src, mapx, mapy, border=0, cval=0):
+    """cv2.remap(src, mapx, mapy, INTER_LINEAR, borderMode=CONSTANT(0)|REPLICATE(1)) for uint8 [H][W] or [H][W][C]."""
+    src = np.ascontiguousarray(src, np.uint8)
+    mapx = np.ascontiguousarray(mapx, np.float32)
+    mapy = np.ascontiguousarray(mapy, np.float32)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dh, dw = mapx.shape
+    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    l = lib()
+    l.nsof_ref_remap_linear_u8.restype = C.c_int
+    l.nsof_ref_remap_linear_u8.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_ssize_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t]
+    _chk(l.nsof_ref_remap_linear_u8(src.ctypes.data, sw * cn, sw, sh, cn, mapx.ctypes.data, mapy.ctypes.data, dw, dw,
+                                    dh, border, cval, out.ctypes.data, dw * cn), "remap")
+    return out
+
+
+def flow_map(flow, rect, sign=-1):
+    """(mapx, mapy) float32 for the crop rect=(x0, y0, x1, y1) of a float32 flow canvas, as prediction.py builds it."""
+    flow = np.ascontiguousarray(flow, np.float32)
+    x0, y0, x1, y1 = rect
+    mx = np.empty((y1 - y0, x1 - x0), np.float32)
+    my = np.empty_like(mx)
+    l = lib()
+    l.nsof_ref_flow_map.restype = C.c_int
+    l.nsof_ref_flow_map.argtypes = [C.c_void_p, C.c_ssize_t] + [C.c_int] * 5 + [C.c_void_p] * 2
+    _chk(l.nsof_ref_flow_map(flow.ctypes.data, 2 * flow.shape[1], x0, y0, x1, y1, sign, mx.ctypes.data,
+                             my.ctypes.data), "flow_map")
+    return mx, my
+
+
+def ssim_u8(a, b, data_range=255.0):
+    """structural_similarity(a, b, data_range=...) for 2-D uint8 views (any strides)."""
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.dtype == np.uint8 and b.dtype == np.uint8 and a.shape == b.shape and a.ndim == 2
+    h, w = a.shape
+    out = C.c_double()
+    l = lib()
+    l.nsof_ref_ssim_u8.restype = C.c_int
+    l.nsof_ref_ssim_u8.argtypes = [C.c_void_p, C.c_ssize_t, C.c_int, C.c_void_p, C.c_ssize_t, C.c_int, C.c_int,
+                                   C.c_int, C.c_double, C.POINTER(C.c_double)]
+    _chk(l.nsof_ref_ssim_u8(a.ctypes.data, a.strides[0], a.strides[1], b.ctypes.data, b.strides[0], b.strides[1], w, h,
+                            data_range, C.byref(out)), "ssim")
+    return out.value

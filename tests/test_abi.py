@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound(nsof_lib):
     assert [lib.nsof_kernel_name(i) for i in range(_lib.K_COUNT)] == [b"prep", b"polyexp", b"flow_upsample",
                                                                      b"update_matrices", b"blur_solve",
                                                                      b"accum_update", b"iterate", b"mask_pack",
-                                                                         b"morph_chain"]
+                                                                         b"morph_chain", b"remap", b"ssim"]
 
 
 def test_geometry_helpers_match_oracle(nsof_lib, oracle):
