@@ -20,12 +20,12 @@ from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, 
                           simulate, simulate_frames, slice_indices, update_state)
 
 from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, frame_to_gray,  # noqa: F401,E402
-                     gating_maps, opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
+                     gating_maps, load_gating_stack, opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
 from .segment import (MORPH_CROSS, MORPH_ELLIPSE, MORPH_RECT, dilate, erode, getStructuringElement, motion_mask,  # noqa: F401,E402
                       motion_mask_dev, process_flow_region, task_results)
 from .predict import (BORDER_CONSTANT, BORDER_REPLICATE, INTER_LINEAR, calculateIntegralError, predict_region,  # noqa: F401,E402
                       predict_region_dev, remap, structural_similarity)
-from .flowviz import flow_to_image, flow_uv_to_colors, make_colorwheel  # noqa: F401,E402
+from .flowviz import flow_to_image, flow_uv_to_colors, make_colorwheel, viz  # noqa: F401,E402
 
 __all__ = ["calcOpticalFlowFarneback", "install", "uninstall", "FarnebackParams", "farneback_batch", "Context",
            "default_context", "simulate", "update_state", "resistance_exp", "Accumulator", "NsofError", "error"]

@@ -58,3 +58,11 @@ def flow_to_image(flow_uv, clip_flow=None, convert_to_bgr=False, max_flow=None):
     u, v = flow_uv[..., 0], flow_uv[..., 1]
     top = np.max(np.sqrt(np.square(u) + np.square(v))) if max_flow is None else max_flow
     return flow_uv_to_colors(u / (top + 1e-5), v / (top + 1e-5), convert_to_bgr)
+
+
+def viz(flo, imgname):
+    """``viz`` of the scripts (optical_flow_seg.py:11-19): colour-code the flow and save it with the channels in
+    B,G,R order, as the reference does (it hands ``flo[:, :, [2, 1, 0]]`` to PIL).  Needs Pillow."""
+    from PIL import Image
+    img = flow_to_image(flo)[:, :, [2, 1, 0]]
+    Image.fromarray(np.ascontiguousarray(img)).save(imgname)

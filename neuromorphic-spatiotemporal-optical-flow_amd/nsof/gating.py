@@ -81,6 +81,13 @@ def frame_to_gray(frame, code="RGB2GRAY"):
     return (acc >> 15).astype(np.uint8)
 
 
+def load_gating_stack(mat_path):
+    """The ``constructed3DMatrix`` stack (rows x cols x slices, device currents in ampere) of a dataset's
+    ``constructed_3D_matrix.mat`` (optical_flow_seg.py:412-413).  Needs scipy; the file is parsed, nothing in it runs."""
+    import scipy.io
+    return scipy.io.loadmat(mat_path)["constructed3DMatrix"]
+
+
 def gating_maps(mem_state, i, cfg):
     """(memimg1, memimg2) for frame pair i from the ``constructed3DMatrix`` stack (seg.py:416-437).
     With ``cfg.bug_compatible`` memimg2 is a copy of memimg1, as in the shipped scripts."""

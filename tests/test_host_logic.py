@@ -76,3 +76,47 @@ def test_shard_bounds(nsof_lib):
             assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_flow_colour_coding_properties(tmp_path):
+    """flow_viz mirror: wheel layout, white at rest, known hues on the axes, 75 % dimming beyond the normaliser, viz()."""
+    import numpy as np
+    from nsof import flowviz
+    wheel = flowviz.make_colorwheel()
+    assert wheel.shape == (55, 3) and wheel[0].tolist() == [255, 0, 0] and wheel[15].tolist() == [255, 255, 0]
+    assert wheel[21].tolist() == [0, 255, 0] and wheel[25].tolist() == [0, 255, 255] and wheel[36].tolist() == [0, 0, 255]
+    flow = np.zeros((4, 4, 2), np.float32)
+    flow[0, 0] = (1, 0)
+    flow[0, 1] = (0, 1)
+    flow[0, 2] = (-1, 0)
+    flow[0, 3] = (0.5, 0)
+    img = flowviz.flow_to_image(flow)
+    assert img.dtype == np.uint8 and img.shape == (4, 4, 3)
+    assert img[1, 1].tolist() == [255, 255, 255]                         # no motion -> white
+    assert img[0, 0].tolist() == [255, 0, 0] and img[0, 2].tolist() == [0, 209, 255]   # +x red, -x azure (wheel[27])
+    assert img[0, 1].tolist() == [255, 229, 0]                           # +y: wheel[13.5]
+    assert img[0, 3].tolist() == [255, 127, 127]                         # half magnitude -> half saturation
+    assert np.array_equal(flowviz.flow_to_image(flow, convert_to_bgr=True), img[..., ::-1])
+    dim = flowviz.flow_to_image(flow, max_flow=0.5)
+    assert dim[0, 0].tolist() == [191, 0, 0]                             # beyond the normaliser: colour * 0.75
+    from PIL import Image
+    flowviz.viz(flow, str(tmp_path / "f.png"))
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "f.png")), img[:, :, [2, 1, 0]])
+
+
+def test_load_gating_stack_and_gray(tmp_path):
+    import numpy as np
+    import scipy.io
+    from nsof import gating
+    stack = np.full((3, 2, 4), 1e-7)
+    stack[1, 1, 2] = 1e-6
+    scipy.io.savemat(tmp_path / "m.mat", {"constructed3DMatrix": stack})
+    got = gating.load_gating_stack(str(tmp_path / "m.mat"))
+    assert got.shape == (3, 2, 4) and got[1, 1, 2] == 1e-6
+    assert gating.current_to_gray(got[:, :, 2])[1, 1] == 255
+    f = np.zeros((2, 2, 3), np.uint8)
+    f[0, 0] = (255, 0, 0)
+    f[1, 1] = (10, 200, 30)
+    assert gating.frame_to_gray(f, "RGB2GRAY")[0, 0] == (255 * 9798 + (1 << 14)) >> 15
+    assert gating.frame_to_gray(f, "BGR2GRAY")[0, 0] == (255 * 3735 + (1 << 14)) >> 15
+    assert gating.frame_to_gray(f)[1, 1] == (10 * 9798 + 200 * 19235 + 30 * 3735 + (1 << 14)) >> 15
