@@ -153,6 +153,115 @@ __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restric
     }
 }
 
+// Resampled level for EXACT decimation by S = 2, 4, 8 (W = S*wk, H = S*hk, W % 16 == 0: the pyr_scale 0.5 pyramids
+// of 1080p/4K frames).  The thread-per-output kernels below issue dozens of narrow loads per output pixel and are
+// bound by the L1's 4 lanes/cycle; here a lane owns 16 adjacent source columns (16/S output pixels) and walks down
+// the output rows of its segment:
+//   * one aligned 16-B load per source row + one halo load per side (the image's own edge reflects out of the
+//     lane's 16 bytes, no extra load),
+//   * the row filter is evaluated only at the columns the resize samples (S*j + S/2 - 1 and the next one), once
+//     per source row, and kept in a register ring of RING >= KS + 1 rows (static slots: the walk is unrolled
+//     over RING / S steps),
+//   * column filter at the two sampled rows, then resize's 2x2 blend (all four weights are exactly 0.5).
+// Same operation order as the other prep kernels (row_filter / col_filter), so the output is bit-identical.
+template <int S, int KS>
+__global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                     ptrdiff_t img_stride, int W, int H, int wk, int hk, int seg_rows,
+                                                     nsof_blur_taps t, float* __restrict__ out)
+{
+    constexpr int R = KS / 2, NPX = 16 / S, NC = 2 * NPX;
+    constexpr int RING = (KS + 1 + S - 1) / S * S, U = RING / S;
+    constexpr int HB = (R + 3) / 4 * 4, HD = HB / 4;          // halo bytes / dwords per side
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = blockIdx.x * 64 + lane;                      // 16-column group
+    const int seg = blockIdx.y * 4 + wave;
+    const int dy0 = seg * seg_rows;
+    if (dy0 >= hk) return;                                     // wave-uniform
+    const int dy1 = min(dy0 + seg_rows, hk);
+    const bool live = 16 * T < W;
+    const int x16 = live ? 16 * T : 0;
+    const bool edge_l = x16 == 0, edge_r = x16 + 16 >= W;
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    float* dst = out + (size_t)blockIdx.z * wk * hk;
+    auto tk = [&](int j) { return t.k[j]; };                   // static index after unrolling
+
+    float ring[RING][NC];
+
+    // row filter of (unreflected) source row r at this lane's sampled columns -> ring[slot]
+    auto load_row = [&](int r, float (&dstrow)[NC]) {
+        const uint8_t* rowp = img + (ptrdiff_t)reflect101(r, H) * row_stride + x16;
+        const uint4 c = *reinterpret_cast<const uint4*>(rowp);
+        unsigned hl[HD], hr[HD];
+        const uint8_t* lp = edge_l ? rowp : rowp - HB;          // edge lanes: any valid address, value unused
+        const uint8_t* rp = edge_r ? rowp : rowp + 16;
+#pragma unroll
+        for (int d = 0; d < HD; d++) {
+            hl[d] = reinterpret_cast<const unsigned*>(lp)[d];
+            hr[d] = reinterpret_cast<const unsigned*>(rp)[d];
+        }
+        const unsigned cw[4] = {c.x, c.y, c.z, c.w};
+        float fb[HB + 16 + HB];
+#pragma unroll
+        for (int b = 0; b < 16; b++) fb[HB + b] = (float)((cw[b >> 2] >> (8 * (b & 3))) & 0xffu);
+#pragma unroll
+        for (int b = 0; b < HB; b++) {
+            // left halo byte b is column x16 - HB + b; at the image edge it reflects to column HB - b (own bytes)
+            const float own_l = fb[HB + (HB - b)];
+            const float ld_l = (float)((hl[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            fb[b] = edge_l ? own_l : ld_l;
+            // right halo byte b is column x16 + 16 + b; at the edge (x16 + 16 == W) it reflects to W - 2 - b
+            const float own_r = fb[HB + 14 - b];
+            const float ld_r = (float)((hr[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            fb[HB + 16 + b] = edge_r ? own_r : ld_r;
+        }
+#pragma unroll
+        for (int n = 0; n < NC; n++) {
+            const int off = HB + S * (n >> 1) + S / 2 - 1 + (n & 1);
+            dstrow[n] = row_filter<KS>(tk, KS, off, [&](int q) { return fb[q]; });
+        }
+    };
+
+    // relative row index rel = r - base, base = first row needed by output row dy0; slot = rel % RING
+    const int base = S * dy0 + S / 2 - 1 - R;
+#pragma unroll
+    for (int i = 0; i <= KS - S; i++) load_row(base + i, ring[i % RING]);
+
+    for (int g = 0; dy0 + g * U < dy1; g++) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int dy = dy0 + g * U + u;
+            if (dy >= dy1) break;                               // wave-uniform
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                load_row(base + S * (g * U + u) + KS - S + 1 + i, ring[(S * u + KS - S + 1 + i) % RING]);
+            }
+            if (live) {
+                float o[NPX];
+#pragma unroll
+                for (int j = 0; j < NPX; j++) {
+                    auto col = [&](int n, int centre) {
+                        return col_filter<KS>(tk, KS, centre, [&](int q) { return ring[(S * u + q) % RING][n]; });
+                    };
+                    const float B00 = col(2 * j, R), B01 = col(2 * j + 1, R);
+                    const float B10 = col(2 * j, R + 1), B11 = col(2 * j + 1, R + 1);
+                    const float t0 = B00 * 0.5f + B01 * 0.5f;
+                    const float t1 = B10 * 0.5f + B11 * 0.5f;
+                    o[j] = t0 * 0.5f + t1 * 0.5f;
+                }
+                float* op = dst + (size_t)dy * wk + NPX * T;
+                if (NPX == 8) {
+                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(op + 4) = make_float4(o[4 % NPX], o[5 % NPX], o[6 % NPX], o[7 % NPX]);
+                } else if (NPX == 4) {
+                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2 % NPX], o[3 % NPX]);
+                } else {
+                    *reinterpret_cast<float2*>(op) = make_float2(o[0], o[1]);
+                }
+            }
+        }
+    }
+}
+
 // Resampled level, generic fallback: one thread per destination pixel, no data sharing.
 __global__ __launch_bounds__(256) void k_prep_naive(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                      ptrdiff_t img_stride, int W, int H, int wk, int hk,
@@ -927,7 +1036,30 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
                             (size_t)rh_cap * rw_cap;
         const bool direct_ok = scale_x >= 1.0 && scale_y >= 1.0 &&
                                (taps.ksize == 3 || taps.ksize == 5);   // larger kernels: registers run out
-        if (direct_ok) {
+        // exact decimation by 2 / 4 / 8 with the kernel sizes the pyr_scale 0.5 pyramid produces
+        const int S = W / wk;
+        const bool decim_ok = W == S * wk && H == S * hk && (W & 15) == 0 && (row_stride & 15) == 0 &&
+                              (img_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+                              ((S == 2 && taps.ksize == 3) || (S == 4 && taps.ksize == 9) ||
+                               (S == 8 && taps.ksize == 19)) &&
+                              H > taps.ksize && getenv("NSOF_PREP_NODECIM") == nullptr;
+        if (decim_ok) {
+            // segments of output rows: multiples of the unroll count, ~16 source rows of warm-up amortised
+            const int U = S == 2 ? 2 : 3;
+            int seg_rows = S == 2 ? 32 : (S == 4 ? 24 : 15);
+            seg_rows = (seg_rows + U - 1) / U * U;
+            const int nseg = (hk + seg_rows - 1) / seg_rows;
+            dim3 grid((W / 16 + 63) / 64, (nseg + 3) / 4, n_img);
+            if (S == 2)
+                hipLaunchKernelGGL((k_prep_decim<2, 3>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride,
+                                   W, H, wk, hk, seg_rows, taps, out);
+            else if (S == 4)
+                hipLaunchKernelGGL((k_prep_decim<4, 9>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride,
+                                   W, H, wk, hk, seg_rows, taps, out);
+            else
+                hipLaunchKernelGGL((k_prep_decim<8, 19>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride,
+                                   W, H, wk, hk, seg_rows, taps, out);
+        } else if (direct_ok) {
             dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
 #define NSOF_PREP_DIRECT(KS)                                                                                       \
     hipLaunchKernelGGL(k_prep_direct<KS>, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk, \

@@ -67,6 +67,30 @@ def test_pyr_level_bit_exact(ctx, oracle, torch_dev, frames, pyr_scale, level, s
     assert np.array_equal(got[1], oracle.pyr_level(frames[shape][1], pyr_scale, level))
 
 
+@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("shape", [(272, 480), (24, 16), (184, 1040), (1080, 1920)])
+def test_pyr_level_exact_decimation_path(ctx, oracle, torch_dev, level, shape):
+    """Dense, 16-byte aligned frames whose size divides by 2^level take the decimating walker kernel
+    (k_prep_decim); same bits as the oracle, and as the generic kernels (NSOF_PREP_NODECIM)."""
+    import torch
+    h, w = shape
+    if h % (1 << level) or w % (1 << level) or h <= (3, 9, 19)[level - 1]:
+        pytest.skip("shape does not decimate exactly at this level")
+    rng = np.random.default_rng(h * 7 + w + level)
+    buf = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    buf[1] = (np.add.outer(np.arange(h), np.arange(w)) % 256).astype(np.uint8)      # ramps: reflect errors show up
+    want = [oracle.pyr_level(buf[i], 0.5, level) for i in range(3)]
+    hk, wk = want[0].shape
+    assert (hk, wk) == (h >> level, w >> level)
+    d = _dev(torch_dev, buf)
+    out = torch.empty((3, hk, wk), dtype=torch.float32, device=torch_dev)
+    ctx.check(ctx._lib.nsof_stage_pyr_level(ctx.ptr, 3, d.data_ptr(), w, h * w, w, h, 0.5, level, out.data_ptr()))
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], want[i]), i
+
+
 @pytest.mark.parametrize("n,sigma", [(1, 1.05), (2, 0.9), (3, 1.1), (5, 1.2), (7, 1.5), (10, 1.05), (4, 0.0)])
 @pytest.mark.parametrize("shape", [(135, 240), (97, 131), (33, 517)])
 def test_polyexp_bit_exact(ctx, oracle, torch_dev, n, sigma, shape):
