@@ -25,6 +25,7 @@ from .segment import (MORPH_CROSS, MORPH_ELLIPSE, MORPH_RECT, dilate, erode, get
                       motion_mask_dev, process_flow_region, task_results)
 from .predict import (BORDER_CONSTANT, BORDER_REPLICATE, INTER_LINEAR, calculateIntegralError, predict_region,  # noqa: F401,E402
                       predict_region_dev, remap, structural_similarity)
+from .frames import compress_image, crop_image, im2double, imresize_lanczos3, process_images  # noqa: F401,E402
 from .flowviz import flow_to_image, flow_uv_to_colors, make_colorwheel, viz  # noqa: F401,E402
 
 __all__ = ["calcOpticalFlowFarneback", "install", "uninstall", "FarnebackParams", "farneback_batch", "Context",

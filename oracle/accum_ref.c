@@ -207,3 +207,73 @@ int nsof_ref_accum_frames(const double* imgs, int n_frames, int H, int W, double
     }
     return 0;
 }
+
+/* ---- compress_image: imresize(double image, [oh ow], 'lanczos3') of simulationcode_v4_transistor_uav.m:111-121 --
+ * MATLAB's imresize is not part of the reference; restated from its published algorithm (imresize.m,
+ * `contributions`): antialiased Lanczos-3 (kernel stretched by 1/scale when shrinking), P = ceil(6/scale) + 2
+ * taps from floor(u - 3/scale), u = x/scale + 0.5(1 - 1/scale), weights normalised, mirrored indices, axis with the
+ * smaller scale first (rows on a tie).  PARITY UNPINNED (no MATLAB/Octave, no stored compressed frames).
+ * Scalar loops, one axis at a time; img [h][w] float64. */
+static double lanczos3(double x)
+{
+    const double eps = 2.220446049250313e-16, pi = 3.14159265358979323846;
+    double f = (sin(pi * x) * sin(pi * x / 3) + eps) / ((pi * pi * x * x / 3) + eps);
+    return fabs(x) < 3 ? f : 0.0;
+}
+
+static void resize_axis(const double* in, int h, int w, int axis, int out_len, double* out)
+{
+    const int in_len = axis == 0 ? h : w;
+    const double scale = (double)out_len / in_len;
+    double kw = 6.0;
+    if (scale < 1) kw /= scale;
+    const int P = (int)ceil(kw) + 2;
+    const int oh = axis == 0 ? out_len : h, ow = axis == 0 ? w : out_len;
+    double* wt = (double*)malloc(sizeof(double) * P);
+    int* idx = (int*)malloc(sizeof(int) * P);
+    for (int o = 0; o < out_len; o++) {
+        const double u = (o + 1) / scale + 0.5 * (1 - 1 / scale);
+        const double left = floor(u - kw / 2);
+        double sum = 0;
+        for (int k = 0; k < P; k++) {
+            const double pos = left + k;   /* 1-based source position */
+            wt[k] = scale < 1 ? scale * lanczos3(scale * (u - pos)) : lanczos3(u - pos);
+            sum += wt[k];
+            long q = ((long)pos - 1) % (2L * in_len);
+            if (q < 0) q += 2L * in_len;
+            idx[k] = (int)(q < in_len ? q : 2L * in_len - 1 - q);
+        }
+        for (int k = 0; k < P; k++) wt[k] /= sum;
+        const int other = axis == 0 ? w : h;
+        for (int j = 0; j < other; j++) {
+            double acc = 0;
+            for (int k = 0; k < P; k++)
+                acc += wt[k] * (axis == 0 ? in[(size_t)idx[k] * w + j] : in[(size_t)j * w + idx[k]]);
+            if (axis == 0) out[(size_t)o * ow + j] = acc;
+            else out[(size_t)j * ow + o] = acc;
+        }
+    }
+    (void)oh;
+    free(wt);
+    free(idx);
+}
+
+int nsof_ref_imresize_lanczos3(const double* img, int h, int w, int oh, int ow, double* out)
+{
+    if (h < 1 || w < 1 || oh < 1 || ow < 1) return -1;
+    const double sh = (double)oh / h, sw = (double)ow / w;
+    if (sh <= sw) {
+        double* tmp = (double*)malloc(sizeof(double) * (size_t)oh * w);
+        if (!tmp) return -2;
+        resize_axis(img, h, w, 0, oh, tmp);
+        resize_axis(tmp, oh, w, 1, ow, out);
+        free(tmp);
+    } else {
+        double* tmp = (double*)malloc(sizeof(double) * (size_t)h * ow);
+        if (!tmp) return -2;
+        resize_axis(img, h, w, 1, ow, tmp);
+        resize_axis(tmp, h, ow, 0, oh, out);
+        free(tmp);
+    }
+    return 0;
+}

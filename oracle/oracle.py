@@ -320,3 +320,15 @@ def ssim_u8(a, b, data_range=255.0):
     _chk(l.nsof_ref_ssim_u8(a.ctypes.data, a.strides[0], a.strides[1], b.ctypes.data, b.strides[0], b.strides[1], w, h,
                             data_range, C.byref(out)), "ssim")
     return out.value
+
+
+def imresize_lanczos3(img, oh, ow):
+    """imresize(double image, [oh ow], 'lanczos3') -- see the header of the function in accum_ref.c."""
+    img = np.ascontiguousarray(img, np.float64)
+    h, w = img.shape
+    out = np.empty((oh, ow), np.float64)
+    l = lib()
+    l.nsof_ref_imresize_lanczos3.restype = C.c_int
+    l.nsof_ref_imresize_lanczos3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    _chk(l.nsof_ref_imresize_lanczos3(img.ctypes.data, h, w, oh, ow, out.ctypes.data), "imresize")
+    return out
