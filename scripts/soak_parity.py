@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Parity soak: many seeded (shape, parameter) cases of the whole Farneback call, HIP path vs CPU oracle.
+Not part of the test-suite (minutes of CPU oracle time); prints one JSON summary line.
+
+    python scripts/soak_parity.py [--cases 400] [--seed 7]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "neuromorphic-spatiotemporal-optical-flow_amd")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=7)
+    a = ap.parse_args()
+    os.environ.setdefault("NSOF_SKIP_BUILD", "1")
+    import numpy as np
+    import nsof
+    from nsof import synth
+    from oracle import oracle
+    rng = np.random.default_rng(a.seed)
+    ctx = nsof.Context(0)
+    exact = 0
+    worst = (0.0, None)
+    t0 = time.time()
+    kinds = {"generic": 0, "pow2_aligned": 0, "reference_sets": 0}
+    for case in range(a.cases):
+        kind = ("generic", "pow2_aligned", "reference_sets")[case % 3]
+        if kind == "pow2_aligned":     # sizes that take the exact-decimation pyramid kernels
+            h, w = 8 * int(rng.integers(5, 60)), 16 * int(rng.integers(3, 40))
+            p = (0.5, int(rng.integers(1, 5)), int(rng.integers(2, 18)), int(rng.integers(1, 4)),
+                 int(rng.integers(1, 11)), float(rng.choice([0.0, 1.1, 1.2, 1.5])), 0)
+        elif kind == "reference_sets":  # the three parameter sets of data/*/Parameters.txt on random sizes
+            h, w = int(rng.integers(40, 500)), int(rng.integers(40, 640))
+            p = [(0.5, 3, 15, 3, 5, 1.2, 0), (0.6, 3, 3, 3, 10, 1.05, 0), (0.6, 3, 4, 2, 1, 1.05, 0)][case // 3 % 3]
+        else:
+            h, w = int(rng.integers(33, 400)), int(rng.integers(33, 600))
+            p = (float(rng.choice([0.5, 0.6, 0.75, 0.8, 0.9])), int(rng.integers(0, 7)), int(rng.integers(2, 40)),
+                 int(rng.integers(0, 5)), int(rng.integers(1, 11)), float(rng.choice([0.0, 0.8, 1.1, 1.5, 2.0])), 0)
+        kinds[kind] += 1
+        prev, nxt = synth.make_pair(5000 + case, h, w, shift=(float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5))),
+                                    rot_deg=float(rng.uniform(-1.5, 1.5)))
+        if case % 7 == 0:               # white noise: no structure to track, large/erratic flow
+            prev = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            nxt = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        got = nsof.calcOpticalFlowFarneback(prev, nxt, None, *p, ctx=ctx)
+        want = oracle.farneback(prev, nxt, *p)
+        err = float(np.abs(got - want).max())
+        rel = err / max(1.0, float(np.abs(want).max()))
+        exact += int(err == 0.0)
+        if rel > worst[0]:
+            worst = (rel, {"case": case, "shape": [h, w], "params": list(p), "abs": err,
+                           "max_flow": float(np.abs(want).max())})
+    print(json.dumps({"cases": a.cases, "seed": a.seed, "kinds": kinds, "bit_identical": exact,
+                      "worst_relative_error": worst[0], "worst_case": worst[1],
+                      "seconds": round(time.time() - t0, 1)}))
+
+
+if __name__ == "__main__":
+    main()
