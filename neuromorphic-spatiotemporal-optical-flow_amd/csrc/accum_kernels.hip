@@ -146,28 +146,36 @@ __global__ __launch_bounds__(256) void k_update_sparse(float* __restrict__ w, un
 
 // Fused state update over every pixel (silent_v outside the dead zone, or forced dense).
 // 4 pixels per thread: one 16-B load/store of w and of the mask per lane.
+// SIL_NOOP: silent_v lies in the dead zone [voff, von], where update_state leaves w bit-for-bit unchanged
+// (dw = 0, w already inside [0,1]), so only the slices whose bit is set are replayed (in slice order) -- the pass
+// is then bound by its one read and one write of the state instead of by 32 no-op evaluations per pixel.
+template <bool SIL_NOOP>
 __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, unsigned* __restrict__ mask, size_t n4,
                                                        size_t n, int n_sl, float v_act, float v_sil)
 {
+    auto replay = [&](float ww, unsigned m) {
+        if (SIL_NOOP) {
+            for (; m; m &= m - 1) ww = update_one(ww, v_act);
+        } else {
+            for (int s = 0; s < n_sl; s++) ww = update_one(ww, (m >> s) & 1u ? v_act : v_sil);
+        }
+        return ww;
+    };
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         if (4 * i + 3 < n) {
             float4 ww = reinterpret_cast<float4*>(w)[i];
-            uint4 mm = reinterpret_cast<uint4*>(mask)[i];
+            const uint4 mm = reinterpret_cast<uint4*>(mask)[i];
             if (mm.x | mm.y | mm.z | mm.w) reinterpret_cast<uint4*>(mask)[i] = make_uint4(0, 0, 0, 0);
-            for (int s = 0; s < n_sl; s++) {
-                ww.x = update_one(ww.x, (mm.x >> s) & 1u ? v_act : v_sil);
-                ww.y = update_one(ww.y, (mm.y >> s) & 1u ? v_act : v_sil);
-                ww.z = update_one(ww.z, (mm.z >> s) & 1u ? v_act : v_sil);
-                ww.w = update_one(ww.w, (mm.w >> s) & 1u ? v_act : v_sil);
-            }
+            ww.x = replay(ww.x, mm.x);
+            ww.y = replay(ww.y, mm.y);
+            ww.z = replay(ww.z, mm.z);
+            ww.w = replay(ww.w, mm.w);
             reinterpret_cast<float4*>(w)[i] = ww;
         } else {
             for (size_t j = 4 * i; j < n; j++) {
-                unsigned m = mask[j];
+                const unsigned m = mask[j];
                 mask[j] = 0;
-                float ww = w[j];
-                for (int s = 0; s < n_sl; s++) ww = update_one(ww, (m >> s) & 1u ? v_act : v_sil);
-                w[j] = ww;
+                w[j] = replay(w[j], m);
             }
         }
     }
@@ -435,8 +443,12 @@ extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int
                                            a->w[i], a->mask[i], a->list[i], a->count + i, (int)g, v_act);
                 } else {
                     const size_t n4 = (a->npx + 3) / 4;
-                    hipLaunchKernelGGL(k_update_dense, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream, a->w[i],
-                                       a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v);
+                    if (dead_zone)
+                        hipLaunchKernelGGL(k_update_dense<true>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream,
+                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v);
+                    else
+                        hipLaunchKernelGGL(k_update_dense<false>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream,
+                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v);
                 }
             }
             NSOF_HIP(ctx, hipGetLastError());
