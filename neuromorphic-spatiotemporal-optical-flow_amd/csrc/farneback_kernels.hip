@@ -992,6 +992,97 @@ __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restric
     }
 }
 
+// Upsampling as a row walk: a lane owns 2 adjacent destination columns (one 16-B store per row, so that a store
+// instruction of the wave writes 1 KiB contiguous) and walks down a segment of destination rows.  The (at most 3)
+// source columns its pixels sample are loaded once per SOURCE row, blended horizontally once, and reused by the
+// 2-3 destination rows that sample that source row.  Per-pixel arithmetic and its order are those of
+// k_flow_upsample.
+constexpr int UPW_SEG = 32;
+__global__ __launch_bounds__(256) void k_flow_upsample_walk(const float* __restrict__ src, int sw, int sh,
+                                                             float* __restrict__ dst, int dw, int dh, double scale_x,
+                                                             double scale_y, float mul)
+{
+    constexpr int NPL = 2, NV = NPL + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the 4 waves of a block take adjacent column chunks of the SAME rows: 4 KiB contiguous per row and block
+    const int dx0 = ((blockIdx.x * 4 + wave) * 64 + lane) * NPL;
+    const int y0 = blockIdx.y * UPW_SEG;
+    if (y0 >= dh || (blockIdx.x * 4 + wave) * 64 * NPL >= dw) return;   // wave-uniform
+    const int y1 = min(y0 + UPW_SEG, dh);
+    const bool live = dx0 < dw;
+    int base = 0, i0[NPL], i1[NPL];
+    float a0[NPL], a1[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; i++) {
+        int sx;
+        lin_coord_x(min(dx0 + i, dw - 1), scale_x, sw, sx, a1[i]);
+        a0[i] = 1.f - a1[i];
+        if (i == 0) base = sx;
+        i0[i] = sx - base;                                    // 0..NPL-1 when upsampling
+        i1[i] = min(sx + 1, sw - 1) - base;                   // 0..NPL
+    }
+    const float2* S = reinterpret_cast<const float2*>(src) + (size_t)blockIdx.z * sw * sh;
+    float2* D = reinterpret_cast<float2*>(dst) + (size_t)blockIdx.z * dw * dh;
+    auto pick = [](const float2 (&V)[NV], int k) {
+        float2 r = V[0];
+#pragma unroll
+        for (int q = 1; q < NV; q++) r = k == q ? V[q] : r;
+        return r;
+    };
+    // horizontal blend of source row r at the lane's destination columns
+    auto hrow = [&](int r, float2 (&h)[NPL]) {
+        const float2* row = S + (size_t)r * sw;
+        float2 V[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) V[k] = row[min(base + k, sw - 1)];
+#pragma unroll
+        for (int i = 0; i < NPL; i++) {
+            const float2 p0 = pick(V, i0[i]), p1 = pick(V, i1[i]);
+            h[i].x = p0.x * a0[i] + p1.x * a1[i];
+            h[i].y = p0.y * a0[i] + p1.y * a1[i];
+        }
+    };
+    float2 hA[NPL], hB[NPL];
+    int ra = -1, rb = -1;
+    for (int dy = y0; dy < y1; dy++) {
+        int sy;
+        float b1;
+        lin_coord_y(dy, scale_y, sy, b1);
+        const float b0 = 1.f - b1;
+        const int r0 = clampi(sy, 0, sh - 1), r1 = clampi(sy + 1, 0, sh - 1);
+        if (r0 != ra) {                                       // all branches are wave-uniform
+            if (r0 == rb) {
+#pragma unroll
+                for (int i = 0; i < NPL; i++) hA[i] = hB[i];
+            } else {
+                hrow(r0, hA);
+            }
+            ra = r0;
+        }
+        const bool same = r1 == ra;
+        if (!same && r1 != rb) {
+            hrow(r1, hB);
+            rb = r1;
+        }
+        if (live) {
+            float2 o[NPL];
+#pragma unroll
+            for (int i = 0; i < NPL; i++) {
+                const float2 t0 = hA[i], t1 = same ? hA[i] : hB[i];
+                o[i].x = (t0.x * b0 + t1.x * b1) * mul;
+                o[i].y = (t0.y * b0 + t1.y * b1) * mul;
+            }
+            float2* drow = D + (size_t)dy * dw + dx0;
+            if (dx0 + 1 < dw && (dw & 1) == 0) {
+                *reinterpret_cast<float4*>(drow) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+            } else {
+                drow[0] = o[0];
+                if (dx0 + 1 < dw) drow[1] = o[1];
+            }
+        }
+    }
+}
+
 template <int N>
 void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R)
 {
@@ -1146,6 +1237,14 @@ int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int 
 {
     nsof_prof_scope ps(ctx, NSOF_K_UPSAMPLE);
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    if (dw >= sw && dh >= sh && sw >= 1 && sh >= 1 && dw >= 256 && getenv("NSOF_UPSAMPLE_2X2") == nullptr) {
+        // upsampling: source steps of 0 or 1 between neighbours; rows wide enough for a lane per 2 columns
+        dim3 g(((dw + 1) / 2 + 255) / 256, (dh + UPW_SEG - 1) / UPW_SEG, n_pairs);
+        hipLaunchKernelGGL(k_flow_upsample_walk, g, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x,
+                           scale_y, mul);
+        NSOF_HIP(ctx, hipGetLastError());
+        return NSOF_OK;
+    }
     if (dw >= sw && dh >= sh && sw >= 1 && sh >= 1) {   // upsampling: source steps of 0 or 1 between neighbours
         dim3 g2(((dw + 1) / 2 + 63) / 64, ((dh + 1) / 2 + 3) / 4, n_pairs);
         hipLaunchKernelGGL(k_flow_upsample2x2, g2, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x,

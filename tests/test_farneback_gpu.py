@@ -206,7 +206,9 @@ def test_fused_upsample_iteration_equals_two_stages(ctx, torch_dev, oracle, wins
 
 
 @pytest.mark.parametrize("pyr_scale,src,dst", [(0.5, (68, 120), (135, 240)), (0.6, (58, 79), (97, 131)),
-                                               (0.5, (135, 240), (270, 480))])
+                                               (0.5, (135, 240), (270, 480)), (0.6, (97, 173), (161, 288)),
+                                               (0.5, (100, 129), (200, 257)), (0.75, (120, 300), (160, 400)),
+                                               (0.5, (33, 130), (67, 259)), (0.5, (540, 960), (1080, 1920))])
 def test_flow_upsample_bit_exact(ctx, oracle, torch_dev, pyr_scale, src, dst):
     import torch
     rng = np.random.default_rng(3)
