@@ -165,6 +165,10 @@ int nsof_accum_step_events(nsof_accum* acc, const int16_t* x, const int16_t* y, 
                            int64_t snap_every);
 /* Dense element-wise update_state on DEVICE arrays (event_mem_sim.py:40-57). */
 int nsof_accum_update_state_dev(nsof_ctx* ctx, const float* d_w, const float* d_V, float* d_out, size_t n);
+/* bincount_2d(x, y, H, W) of event_mem_sim.py:100-104: events per pixel, int32 [H][W].  HOST arrays in and out;
+ * events outside the sensor are an error (np.bincount would raise or grow the array). */
+int nsof_accum_bincount_2d(nsof_ctx* ctx, const int16_t* x, const int16_t* y, size_t n, int height, int width,
+                           int32_t* counts_out);
 /* Dense resistance_exp on DEVICE arrays (event_mem_sim.py:60-63). */
 int nsof_accum_resistance_dev(nsof_ctx* ctx, const float* d_w, float* d_out, size_t n);
 /* Copy state to HOST: which = 0 (array A) or 1 (array B, split mode). */

@@ -207,6 +207,14 @@ __global__ __launch_bounds__(64) void k_frame_step(const double* __restrict__ a,
     res[i] = RON / exp(-lambda * (1 - ww));
 }
 
+// bincount_2d (event_mem_sim.py:100-104): events per pixel.
+__global__ __launch_bounds__(256) void k_bincount(const short* __restrict__ x, const short* __restrict__ y, size_t n,
+                                                   int W, int* __restrict__ counts)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        atomicAdd(&counts[(size_t)y[i] * W + x[i]], 1);
+}
+
 inline int grid_for(size_t n, int cap = 4096)
 {
     size_t g = (n + 255) / 256;
@@ -468,6 +476,38 @@ extern "C" int nsof_accum_update_state_dev(nsof_ctx* ctx, const float* d_w, cons
     nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
     hipLaunchKernelGGL(k_update_state, dim3(grid_for(n)), dim3(256), 0, ctx->stream, d_w, d_V, d_out, n);
     NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// Host arrays in, host histogram out (the reference calls it on the events of one slice).
+extern "C" int nsof_accum_bincount_2d(nsof_ctx* ctx, const int16_t* x, const int16_t* y, size_t n, int height,
+                                      int width, int32_t* counts_out)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (!counts_out || (n && (!x || !y))) return nsof_set_error(ctx, NSOF_EINVAL, "null pointer");
+    if (height < 1 || width < 1) return nsof_set_error(ctx, NSOF_ESHAPE, "empty sensor");
+    for (size_t i = 0; i < n; i++)   // np.bincount raises on negative values; out-of-range ones would grow the array
+        if (x[i] < 0 || y[i] < 0 || x[i] >= width || y[i] >= height)
+            return nsof_set_error(ctx, NSOF_EINVAL, "event %zu (%d,%d) outside the %dx%d sensor", i, (int)x[i],
+                                  (int)y[i], width, height);
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)height * width;
+    const size_t szE = (n * 2 + 255) & ~(size_t)255, szC = (npx * 4 + 255) & ~(size_t)255;
+    int rc = nsof_ws_reserve(ctx, &ctx->stage, &ctx->stage_bytes, 2 * szE + szC);
+    if (rc) return rc;
+    short* dx = (short*)ctx->stage;
+    short* dy = (short*)((char*)ctx->stage + szE);
+    int* dc = (int*)((char*)ctx->stage + 2 * szE);
+    NSOF_HIP(ctx, hipMemsetAsync(dc, 0, npx * 4, ctx->stream));
+    if (n) {
+        NSOF_HIP(ctx, hipMemcpyAsync(dx, x, n * 2, hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipMemcpyAsync(dy, y, n * 2, hipMemcpyHostToDevice, ctx->stream));
+        nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+        hipLaunchKernelGGL(k_bincount, dim3(grid_for(n)), dim3(256), 0, ctx->stream, dx, dy, n, width, dc);
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    NSOF_HIP(ctx, hipMemcpyAsync(counts_out, dc, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NSOF_OK;
 }
 

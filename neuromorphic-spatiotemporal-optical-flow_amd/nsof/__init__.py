@@ -16,8 +16,9 @@ from .errors import NsofError, error  # noqa: F401
 from .context import Context, default_context  # noqa: F401
 from .farneback import (FarnebackParams, calcOpticalFlowFarneback, effective_levels, farneback_batch, farneback_sequence,  # noqa: F401
                         install, level_size, uninstall)
-from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, load_events, resistance_exp,  # noqa: F401
-                          simulate, simulate_frames, slice_indices, update_state)
+from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, bincount_2d,  # noqa: F401
+                          generate_synthetic_events, load_events, resistance_exp, simulate, simulate_frames,
+                          slice_indices, update_state)
 
 from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray, dataset_config, frame_to_gray,  # noqa: F401,E402
                      gating_maps, load_gating_stack, opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)

@@ -45,6 +45,7 @@ SIGNATURES = {
     "nsof_accum_step_events": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "nsof_accum_update_state_dev": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "nsof_accum_resistance_dev": (_i, [_vp, _vp, _vp, _sz]),
+    "nsof_accum_bincount_2d": (_i, [_vp, _vp, _vp, _sz, _i, _i, _vp]),
     "nsof_accum_read_w": (_i, [_vp, _i, _vp]),
     "nsof_accum_read_resistance": (_i, [_vp, _i, _vp]),
     "nsof_accum_snapshot_count": (_i64, [_vp]),

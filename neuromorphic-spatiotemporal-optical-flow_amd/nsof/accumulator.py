@@ -77,6 +77,51 @@ def slice_indices(t, slice_us):
         yield slice(int(idx[i]), int(idx[i + 1]))
 
 
+def bincount_2d(x, y, H, W, *, ctx=None):  # noqa: N803
+    """``bincount_2d`` of event_mem_sim.py:100-104: events per pixel, int32 [H][W] (atomic adds on the GPU)."""
+    ctx = ctx or default_context()
+    x, y = np.asarray(x), np.asarray(y)
+    if x.shape != y.shape or x.ndim != 1:
+        raise NsofValueError("bincount_2d: x and y must be 1-D arrays of one length")
+    if x.size and (x.min() < -32768 or x.max() > 32767 or y.min() < -32768 or y.max() > 32767):
+        raise NsofValueError("bincount_2d: coordinates outside the int16 range of /CD/events")
+    x16, y16 = np.ascontiguousarray(x, np.int16), np.ascontiguousarray(y, np.int16)
+    out = np.empty((int(H), int(W)), np.int32)
+    ctx.check(ctx._lib.nsof_accum_bincount_2d(ctx.ptr, x16.ctypes.data, y16.ctypes.data, x16.size, int(H), int(W),
+                                              out.ctypes.data), "bincount_2d")
+    return out
+
+
+def generate_synthetic_events(H=240, W=320, box_h=50, box_w=50, speed_pps=300, duration_s=1.5):  # noqa: N803
+    """``generate_synthetic_events`` of event_mem_sim.py:109-158: a white box moving left to right; ON (+1) events
+    on the pixels it newly covers, OFF (-1) on the ones it leaves, one frame every ``DT`` seconds.  Same event order
+    as the reference (per step: ON pixels in row-major order, then OFF pixels).  Host generator (test input)."""
+    t_step_us = int(DT * 1_000_000)
+    duration_us = int(duration_s * 1_000_000)
+    y0 = (H - box_h) // 2
+    rows = np.arange(y0, min(y0 + box_h, H))
+    rows = rows[rows >= 0]
+    xs, ys, ps, ts = [], [], [], []
+    prev = (0, 0)                                   # covered column range [a, b) of the previous frame
+    for t_us in range(0, duration_us, t_step_us):
+        start = int((t_us / 1_000_000) * speed_pps)
+        end = start + box_w
+        cur = (max(0, start), min(W, end)) if (start < W and end > 0) else (0, 0)
+        cols_cur = np.arange(cur[0], cur[1])
+        cols_prev = np.arange(prev[0], prev[1])
+        for cols, pol in ((np.setdiff1d(cols_cur, cols_prev), 1), (np.setdiff1d(cols_prev, cols_cur), -1)):
+            if cols.size and rows.size:
+                yy, xx = np.meshgrid(rows, cols, indexing="ij")   # row-major, like np.where
+                xs.append(xx.ravel()); ys.append(yy.ravel())
+                ps.append(np.full(xx.size, pol)); ts.append(np.full(xx.size, t_us))
+        prev = cur
+    if not xs:
+        e = np.array([], dtype=int)
+        return e, e.copy(), e.copy(), e.copy()
+    return (np.concatenate(xs).astype(int), np.concatenate(ys).astype(int), np.concatenate(ps).astype(int),
+            np.concatenate(ts).astype(int))
+
+
 def load_events(h5_path):
     """``load_events`` of event_mem_sim.py:69-75 (needs h5py; sensor size inferred from the data)."""
     import h5py

@@ -163,3 +163,24 @@ def test_output_files_match_reference_format(nsof_lib, ctx, tmp_path):
         m1 = json.load(f)
     assert m1["scheme"] == "boxcar" and m1["polarity"] is None and m1["theta_events"] == 1
     assert not (tmp_path / "one.V2_b.npz").exists()
+
+
+@pytest.mark.gpu
+def test_bincount_2d_matches_reference_and_numpy(nsof_lib):
+    """bincount_2d against the histograms the reference produced and against np.bincount."""
+    import numpy as np
+    from conftest import golden_path
+    g = np.load(golden_path("synth_events.npz"))
+    x, y = g["default_x"], g["default_y"]
+    got = nsof_lib.bincount_2d(x, y, 240, 320)
+    assert got.dtype == np.int32 and np.array_equal(got, g["hist_all"])
+    assert np.array_equal(nsof_lib.bincount_2d(x[:2000], y[:2000], 145, 320), g["hist_first_2000"])
+    rng = np.random.default_rng(1)
+    xs, ys = rng.integers(0, 333, 200_000), rng.integers(0, 77, 200_000)
+    xs[:5000] = 7                                    # a hot pixel: many atomics on one address
+    ys[:5000] = 9
+    want = np.bincount(ys.astype(np.int64) * 333 + xs, minlength=77 * 333).reshape(77, 333).astype(np.int32)
+    assert np.array_equal(nsof_lib.bincount_2d(xs, ys, 77, 333), want)
+    assert nsof_lib.bincount_2d(np.array([], int), np.array([], int), 4, 5).sum() == 0
+    with pytest.raises(nsof_lib.NsofError):
+        nsof_lib.bincount_2d(np.array([5]), np.array([0]), 4, 5)

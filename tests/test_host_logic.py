@@ -120,3 +120,19 @@ def test_load_gating_stack_and_gray(tmp_path):
     assert gating.frame_to_gray(f, "RGB2GRAY")[0, 0] == (255 * 9798 + (1 << 14)) >> 15
     assert gating.frame_to_gray(f, "BGR2GRAY")[0, 0] == (255 * 3735 + (1 << 14)) >> 15
     assert gating.frame_to_gray(f)[1, 1] == (10 * 9798 + 200 * 19235 + 30 * 3735 + (1 << 14)) >> 15
+
+
+def test_generate_synthetic_events_matches_reference_output():
+    """event_mem_sim.generate_synthetic_events: same events, same order, as the arrays the reference
+    itself produced (tests/golden/synth_events.npz, generated by gen_synth_events_golden.py)."""
+    import numpy as np
+    from conftest import golden_path
+    from nsof.accumulator import generate_synthetic_events
+    g = np.load(golden_path("synth_events.npz"))
+    for name, kw in {"default": {}, "small": dict(H=60, W=90, box_h=20, box_w=11, speed_pps=700, duration_s=0.2)}.items():
+        x, y, p, t = generate_synthetic_events(**kw)
+        assert x.dtype.kind == "i" and len(x) == len(g[f"{name}_x"])
+        for got, key in ((x, "x"), (y, "y"), (p, "p"), (t, "t")):
+            assert np.array_equal(got, g[f"{name}_{key}"]), (name, key)
+    x, y, p, t = generate_synthetic_events(duration_s=0.0)
+    assert x.size == y.size == p.size == t.size == 0
