@@ -49,3 +49,89 @@ def gated_flow(gray_map, prev, nxt, cfg, flow_fn=None):
     """Flow of a frame pair restricted to the ROI(s) the gating map selects (``opticalFlow3D`` of the reference)."""
     kw = {} if flow_fn is None else {"flow_fn": flow_fn}
     return gating.opticalFlow3D(gray_map, gray_map, prev, nxt, cfg.MEMSIZE, cfg.MEMSIZE, cfg, **kw)
+
+
+# ---- the segmentation experiment of optical_flow_seg.py (__main__, :399-632) as a function --------------------------
+SEG_CSV_COLUMNS = ["Frame_Pair", "Original_Flow_Time", "Mem_Flow_Time", "Flow_Time_Improvement",
+                   "Flow_Time_Improvement_Percent", "Original_Seg_Time", "Mem_Seg_Time", "Combination_Time",
+                   "Original_PA", "Mem_PA", "Region_Percent", "Cal_Times", "Velocity_Times"]   # seg.py:365-379
+
+
+def calculate_pixel_accuracy(image1, image2):
+    """seg.py:383-387: share of identical pixels, in percent."""
+    return float(np.sum(image1 == image2)) / image1.size * 100
+
+
+def run_segmentation(frames_bgr, gt_masks_bgr, mem_state, cfg, names=None, csv_path=None, seg_th=1, merge_flag=False,
+                     flow_fn=None, mask_fn=None):
+    """The main loop of optical_flow_seg.py for a sequence held in memory: for every pair (i, i+1), i < n-2, the gated
+    flow + segmentation ("Mem") and the full-frame flow + segmentation ("Original"), their times, their pixel
+    accuracies against the ground-truth mask of frame i+1, and the CSV row the script writes (same 13 columns, same
+    formatting).  ``frames_bgr`` / ``gt_masks_bgr``: uint8 [H][W][3] as ``cv2.imread`` returns them; ``mem_state``: the
+    ``constructed3DMatrix`` stack.  ``flow_fn`` / ``mask_fn`` default to the GPU path (``calcOpticalFlowFarneback``,
+    ``segment.motion_mask``); tests inject the CPU oracle.  Returns ``(rows, mean_mem_accuracy, mean_original_accuracy)``."""
+    import csv
+    import time
+
+    from . import segment
+    from .farneback import calcOpticalFlowFarneback
+    flow_fn = flow_fn or calcOpticalFlowFarneback
+    mask_fn = mask_fn or (lambda f: segment.motion_mask(f, seg_th))
+    names = names or [f"{i + 1}.jpg" for i in range(len(frames_bgr))]
+    rows, acc_mem, acc_orig = [], 0.0, 0.0
+    if csv_path:
+        with open(csv_path, "w", newline="") as fh:
+            csv.writer(fh).writerow(SEG_CSV_COLUMNS)
+    for i in range(len(frames_bgr) - 2):
+        cfg.mem_opticalflow_times.clear(); cfg.mem_cal_times.clear(); cfg.mem_velocity_times.clear()
+        memimg1, memimg2 = gating.gating_maps(mem_state, i, cfg)
+        prev_gray = gating.frame_to_gray(frames_bgr[i], "RGB2GRAY")
+        next_gray = gating.frame_to_gray(frames_bgr[i + 1], "RGB2GRAY")
+        gt = np.where(gating.frame_to_gray(gt_masks_bgr[i + 1], "BGR2GRAY") > 127, np.uint8(255), np.uint8(0))
+        h, w = next_gray.shape
+        out = gating.opticalFlow3D(memimg1, memimg2, prev_gray, next_gray, cfg.MEMSIZE, cfg.MEMSIZE, cfg,
+                                   flow_fn=flow_fn)
+        flow, region_list = -out[0], out[3]
+        if cfg.FLAG == 1:
+            num_labels, regions = out[4], out[5]
+        else:
+            regions = out[4]
+            num_labels = 2 if tuple(regions) != (0, 0, 0, 0) else 1
+        # Mem segmentation (task_results, seg.py:253-320)
+        t0 = time.time()
+        motion = np.zeros((h, w), np.uint8)
+        t_comb = 0.0
+        if num_labels > 1:
+            if cfg.FLAG == 1 and merge_flag:
+                pad = 20
+                boxes = [(max(0, min(r[0] for r in regions) - pad), max(0, min(r[1] for r in regions) - pad),
+                          min(w, max(r[2] for r in regions) + pad), min(h, max(r[3] for r in regions) + pad))]
+            else:
+                boxes = list(regions) if cfg.FLAG == 1 else [tuple(regions)]
+            t_comb = time.time() - t0
+            for x0, y0, x1, y1 in boxes:
+                if x1 > x0 and y1 > y0:
+                    motion[y0:y1, x0:x1] = mask_fn(np.ascontiguousarray(flow[y0:y1, x0:x1], np.float32))
+        t_mem_seg = time.time() - t0
+        # Original: full-frame flow and segmentation (seg.py:493-537)
+        t0 = time.time()
+        flow1 = -flow_fn(prev_gray, next_gray, None, **cfg.farneback_params.as_kwargs())
+        t_orig_flow = time.time() - t0
+        t0 = time.time()
+        motion1 = mask_fn(np.ascontiguousarray(flow1, np.float32))
+        t_orig_seg = time.time() - t0
+        a_mem, a_orig = calculate_pixel_accuracy(motion, gt), calculate_pixel_accuracy(motion1, gt)
+        acc_mem += a_mem
+        acc_orig += a_orig
+        t_mem_flow = cfg.mem_opticalflow_times[0]
+        imp = t_orig_flow - t_mem_flow
+        row = [f"{names[i + 1]}-{names[i]}", f"{t_orig_flow:.4f}", f"{t_mem_flow:.4f}", f"{imp:.4f}",
+               f"{imp / t_orig_flow * 100:.2f}", f"{t_orig_seg:.4f}", f"{t_mem_seg:.4f}", f"{t_comb:.4f}",
+               f"{a_orig:.4f}", f"{a_mem:.4f}", region_list, ";".join(f"{t:.4f}" for t in cfg.mem_cal_times),
+               ";".join(f"{t:.4f}" for t in cfg.mem_velocity_times)]
+        rows.append(row)
+        if csv_path:
+            with open(csv_path, "a", newline="") as fh:
+                csv.writer(fh).writerow(row)
+    n = max(len(rows), 1)
+    return rows, acc_mem / n, acc_orig / n

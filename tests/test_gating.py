@@ -151,3 +151,35 @@ def test_events_to_roi_to_flow_pipeline(nsof_lib, ctx):
     flow, _, _, _, rect = pipeline.gated_flow(g, prev, nxt, cfg, flow_fn=fl)
     x0, y0, x1, y1 = rect
     assert flow[y0:y1, x0:x1].any() and not flow[:max(y0 - 1, 0)].any()
+
+
+def test_segmentation_harness_rows_and_csv(nsof_lib, oracle, tmp_path):
+    """run_segmentation = the main loop of optical_flow_seg.py: CSV schema and formatting, accuracies, gating per
+    pair -- here with the CPU oracle injected as flow / mask backend (the GPU backends are the defaults)."""
+    import csv
+    import json
+    from conftest import golden_path
+    from nsof import pipeline, synth
+    g = json.load(open(golden_path("gating_maps.json")))["grasp"]
+    stack = np.stack([np.array([[float(v) for v in row] for row in g["slices"][k]]) for k in ("0", "1", "2")], -1)
+    hm, wm = stack.shape[:2]
+    cfg = nsof_lib.dataset_config("grasp", MEMSIZE=16, EXTEND_HEIGHT_UPPER=4, EXTEND_HEIGHT_LOWER=4,
+                                  EXTEND_WIDTH_LEFT=4, EXTEND_WIDTH_RIGHT=4)
+    h, w = hm * 16, wm * 16
+    frames = []
+    for k in range(3):
+        a, _ = synth.make_pair(40 + k, h, w)
+        frames.append(np.repeat(a[..., None], 3, 2))
+    gts = [np.zeros((h, w, 3), np.uint8) for _ in range(3)]
+    gts[1][10:40, 20:60] = 255
+    far = lambda a, b, _f, **kw: oracle.farneback(a, b, **kw)  # noqa: E731
+    rows, acc_mem, acc_orig = pipeline.run_segmentation(frames, gts, stack, cfg, csv_path=str(tmp_path / "r.csv"),
+                                                        flow_fn=far, mask_fn=lambda f: oracle.motion_mask(f, 1.0, 10, 5))
+    assert len(rows) == 1 and len(rows[0]) == len(pipeline.SEG_CSV_COLUMNS) == 13
+    assert rows[0][0] == "2.jpg-1.jpg" and 0 <= acc_mem <= 100 and 0 <= acc_orig <= 100
+    with open(tmp_path / "r.csv") as fh:
+        got = list(csv.reader(fh))
+    assert got[0] == pipeline.SEG_CSV_COLUMNS and got[1][0] == "2.jpg-1.jpg" and len(got) == 2
+    for col in (1, 2, 3, 5, 6, 7, 8, 9):
+        assert len(got[1][col].split(".")[1]) == 4          # '%.4f'
+    assert pipeline.calculate_pixel_accuracy(np.array([[1, 2]]), np.array([[1, 3]])) == 50.0
