@@ -183,3 +183,27 @@ def test_segmentation_harness_rows_and_csv(nsof_lib, oracle, tmp_path):
     for col in (1, 2, 3, 5, 6, 7, 8, 9):
         assert len(got[1][col].split(".")[1]) == 4          # '%.4f'
     assert pipeline.calculate_pixel_accuracy(np.array([[1, 2]]), np.array([[1, 3]])) == 50.0
+
+
+@pytest.mark.gpu
+def test_segmentation_harness_gpu_equals_oracle_backends(nsof_lib, oracle):
+    import json
+    from conftest import golden_path
+    from nsof import pipeline, synth
+    g = json.load(open(golden_path("gating_maps.json")))["grasp"]
+    stack = np.stack([np.array([[float(v) for v in row] for row in g["slices"][k]]) for k in ("0", "1", "2", "3")], -1)
+    hm, wm = stack.shape[:2]
+    h, w = hm * 16, wm * 16
+    frames = [np.repeat(synth.make_pair(70 + k, h, w)[0][..., None], 3, 2) for k in range(4)]
+    gts = [np.zeros((h, w, 3), np.uint8) for _ in range(4)]
+    gts[2][30:80, 40:100] = 255
+    res = []
+    for backend in ("gpu", "oracle"):
+        cfg = nsof_lib.dataset_config("grasp", MEMSIZE=16, EXTEND_HEIGHT_UPPER=4, EXTEND_HEIGHT_LOWER=4,
+                                      EXTEND_WIDTH_LEFT=4, EXTEND_WIDTH_RIGHT=4)
+        kw = {} if backend == "gpu" else dict(flow_fn=lambda a, b, _f, **k: oracle.farneback(a, b, **k),
+                                              mask_fn=lambda f: oracle.motion_mask(f, 1.0, 10, 5))
+        res.append(pipeline.run_segmentation(frames, gts, stack, cfg, **kw))
+    assert len(res[0][0]) == 2
+    assert res[0][1:] == res[1][1:]                                   # mean accuracies identical
+    assert [r[8:11] for r in res[0][0]] == [r[8:11] for r in res[1][0]]   # per-pair accuracies and region shares
