@@ -86,3 +86,49 @@ def run_sharded(prev_all, next_all, n_total, shape, device, compute, src=0):
     p, q = scatter_pairs(prev_all, next_all, n_total, shape, device, src)
     flow = compute(p, q)
     return gather_flows(flow, n_total, dst=src)
+
+
+# ---- accumulator: row bands --------------------------------------------------------------
+def band_bounds(height, world):
+    """Row band [y0, y1) of every rank: pixels are independent, so the H x W state splits by rows with no halo."""
+    return shard_bounds(height, world)
+
+
+def events_in_band(x, y, p, t, y0, y1):
+    """The events of rows [y0, y1) with y shifted to the band, in stream order, plus their indices in the stream."""
+    import numpy as np
+    y = np.asarray(y)
+    sel = np.nonzero((y >= y0) & (y < y1))[0]
+    return np.asarray(x)[sel], y[sel] - y0, np.asarray(p)[sel], np.asarray(t)[sel], sel
+
+
+def band_slice_bounds(t_all, t_band, slice_us):
+    """Slice boundaries of a band's events on the GLOBAL slice grid (``slice_indices`` uses the first and last
+    timestamp of the whole stream, event_mem_sim.py:78-83)."""
+    import numpy as np
+    t_all = np.asarray(t_all)
+    bounds = np.arange(t_all[0], t_all[-1] + slice_us, slice_us)
+    return np.searchsorted(np.asarray(t_band), bounds, side="left").astype(np.int64)
+
+
+def simulate_banded(x, y, p, t, sensor_hw, slice_us, simulate_band, dst=0):
+    """Scheme-1 accumulator over row bands, one band per rank: every rank filters the (replicated, tiny) event stream
+    to its band, runs ``simulate_band(xb, yb, pb, tb, idx_b, (rows, W)) -> w [rows][W] float32`` (on a GPU:
+    ``Accumulator(rows, W, 1, ...).step(...)`` then ``.w()``), and the bands are gathered on ``dst`` (the only
+    collective).  Scheme 2 couples pixels through the slice's first/last timestamps and is run per independent
+    stream instead."""
+    import numpy as np
+    rank, world = dist.get_rank(), dist.get_world_size()
+    H, W = sensor_hw  # noqa: N806
+    y0, y1 = band_bounds(H, world)[rank]
+    xb, yb, pb, tb, _ = events_in_band(x, y, p, t, y0, y1)
+    idx = band_slice_bounds(t, tb, slice_us)
+    w_local = torch.as_tensor(np.ascontiguousarray(simulate_band(xb, yb, pb, tb, idx, (y1 - y0, W)), np.float32))
+    cap = max(hi - lo for lo, hi in band_bounds(H, world))
+    buf = torch.zeros((cap, W), dtype=torch.float32, device=w_local.device)
+    buf[:y1 - y0] = w_local
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, parts, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(band_bounds(H, world))], 0)

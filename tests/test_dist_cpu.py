@@ -62,3 +62,47 @@ def test_scatter_compute_gather_world2(n_total):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def _band_worker(rank, world, port, ret):
+    for p_ in (ROOT, PKG):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from nsof import dist as nd
+    from nsof import synth
+    from oracle import oracle
+    nd.init_from_env("gloo")
+    H, W = 47, 64                                       # odd height: bands of 24 and 23 rows
+    x, y, p, t = synth.make_events(11, W, H, 3000, 40_000, box=(12, 9))
+
+    def band(xb, yb, pb, tb, idx, hw):                  # stand-in for the per-rank GPU accumulator: the CPU oracle
+        w = np.full(hw, 0.5, np.float32)
+        for s in range(len(idx) - 1):
+            V = np.zeros(hw, np.float32)
+            V[yb[idx[s]:idx[s + 1]], xb[idx[s]:idx[s + 1]]] = -6.0
+            w = oracle.accum_update_state(w, V)
+        return w
+
+    out = nd.simulate_banded(x, y, p, t, (H, W), 1000, band)
+    if rank == 0:
+        full = oracle.accum_simulate(x, y, p, t, H, W, 1, "split", 1000, -6.0, 0.0)["w_final"]
+        ret.put(bool(np.array_equal(out.numpy(), full)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_accumulator_row_bands_world2():
+    """Row-band sharding of the accumulator (scheme 1): two ranks, each its band on the global slice grid, gathered
+    state == the unsharded run."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
