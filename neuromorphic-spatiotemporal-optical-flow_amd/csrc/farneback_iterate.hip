@@ -509,8 +509,12 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
                 o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
             }
             float2* dst = Fout + (size_t)yo * W + xo;
-            dst[0] = o[0];
-            if (xo + 1 < W) dst[1] = o[1];
+            if (xo + 1 < W && (W & 1) == 0) {   // xo is even: 16-B aligned
+                nsof_store_stream4(reinterpret_cast<float*>(dst), o[0].x, o[0].y, o[1].x, o[1].y);
+            } else {
+                dst[0] = o[0];
+                if (xo + 1 < W) dst[1] = o[1];
+            }
         }
 #endif
         // column sums of the next step go to the other buffer: no barrier needed in between

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restric
             o.y = (hm[1] + hp[1]) * k1 + h0[1] * k0;
             o.z = (hm[2] + hp[2]) * k1 + h0[2] * k0;
             o.w = (hm[3] + hp[3]) * k1 + h0[3] * k0;
-            *reinterpret_cast<float4*>(dst + (size_t)y * W + x) = o;
+            nsof_store_stream4(dst + (size_t)y * W + x, o.x, o.y, o.z, o.w);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) { hm[i] = h0[i]; h0[i] = hp[i]; }
@@ -250,12 +250,12 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
                 }
                 float* op = dst + (size_t)dy * wk + NPX * T;
                 if (NPX == 8) {
-                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
-                    *reinterpret_cast<float4*>(op + 4) = make_float4(o[4 % NPX], o[5 % NPX], o[6 % NPX], o[7 % NPX]);
+                    nsof_store_stream4(op, o[0], o[1], o[2], o[3]);
+                    nsof_store_stream4(op + 4, o[4 % NPX], o[5 % NPX], o[6 % NPX], o[7 % NPX]);
                 } else if (NPX == 4) {
-                    *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2 % NPX], o[3 % NPX]);
+                    nsof_store_stream4(op, o[0], o[1], o[2 % NPX], o[3 % NPX]);
                 } else {
-                    *reinterpret_cast<float2*>(op) = make_float2(o[0], o[1]);
+                    nsof_store_stream2(op, o[0], o[1]);
                 }
             }
         }
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
             // channel 4 of the lane's 4 pixels: one 16-B store
             float* c4 = reinterpret_cast<float*>(Rb) + 4u * plane + opix;
             if ((W & 3) == 0) {
-                *reinterpret_cast<float4*>(c4) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                nsof_store_stream4(c4, o4[0], o4[1], o4[2], o4[3]);
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; p++)
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
             for (int k = 0; k < 4; k++) {
                 const int px = 64 * k + lane;   // pixel within the strip row
                 const float4 v = st[wave][px];
-                if (px < G::SW && yo2 < ye && x0 + px < W) q4[px] = v;
+                if (px < G::SW && yo2 < ye && x0 + px < W) nsof_store_stream4(reinterpret_cast<float*>(q4 + px), v.x, v.y, v.z, v.w);
             }
         }
         // no second barrier: the next step writes the other LDS buffer (st is private to a wave)
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restric
         }
         float2* drow = D + (size_t)(dy0 + i) * dw + dx0;
         if (dx0 + 1 < dw && (dw & 1) == 0)
-            *reinterpret_cast<float4*>(drow) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+            nsof_store_stream4(reinterpret_cast<float*>(drow), o[0].x, o[0].y, o[1].x, o[1].y);
         else {
             drow[0] = o[0];
             if (dx0 + 1 < dw) drow[1] = o[1];
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_flow_upsample_walk(const float* __restr
             }
             float2* drow = D + (size_t)dy * dw + dx0;
             if (dx0 + 1 < dw && (dw & 1) == 0) {
-                *reinterpret_cast<float4*>(drow) = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+                nsof_store_stream4(reinterpret_cast<float*>(drow), o[0].x, o[0].y, o[1].x, o[1].y);
             } else {
                 drow[0] = o[0];
                 if (dx0 + 1 < dw) drow[1] = o[1];
