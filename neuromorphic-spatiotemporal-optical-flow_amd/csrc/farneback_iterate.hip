@@ -541,14 +541,29 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
 
     const int tid = threadIdx.x, col = tid % COLS;
     const int role = __builtin_amdgcn_readfirstlane(tid / COLS);   // wave-uniform: 0 consumer, 1/2 producers
-    const int x0 = blockIdx.x * SW;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.
+    // With the natural (strip, pair) order the 8 strips of a pair land on 8 different L2s and their shared halo
+    // columns and gather rows are fetched once per XCD; remapped, an XCD owns whole pairs.
+    int strip = blockIdx.x, pair = blockIdx.z;
+#ifndef NSOF_NO_XCD_REMAP
+    {
+        const unsigned total = gridDim.x * gridDim.z;
+        if ((total & 7u) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+            const unsigned j = (lin & 7u) * (total >> 3) + (lin >> 3);
+            pair = (int)(j / gridDim.x);
+            strip = (int)(j - (unsigned)pair * gridDim.x);
+        }
+    }
+#endif
+    const int x0 = strip * SW;
     const int xc = clampi(x0 - MH + col, 0, W - 1);
     const size_t plane = (size_t)W * H;
-    const Planes R0 = planes_of(R0b + (size_t)blockIdx.z * pair_stride, plane);
-    const Planes R1 = planes_of(R1b + (size_t)blockIdx.z * pair_stride, plane);
+    const Planes R0 = planes_of(R0b + (size_t)pair * pair_stride, plane);
+    const Planes R1 = planes_of(R1b + (size_t)pair * pair_stride, plane);
     FlowSrc<UPS> F;
     if constexpr (UPS) {
-        F.base = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * ups.sw * ups.sh * 8;
+        F.base = reinterpret_cast<const char*>(flow_in) + (size_t)pair * ups.sw * ups.sh * 8;
         F.sw = ups.sw;
         F.sh = ups.sh;
         F.scale_y = ups.scale_y;
@@ -557,11 +572,11 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
         F.a0 = 1.f - F.a1;
         F.c1 = min(F.sx + 1, ups.sw - 1);
     } else {
-        F.base = reinterpret_cast<const char*>(flow_in) + (size_t)blockIdx.z * plane * 8;
+        F.base = reinterpret_cast<const char*>(flow_in) + (size_t)pair * plane * 8;
         F.W = (unsigned)W;
         F.xc = (unsigned)xc;
     }
-    float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)blockIdx.z * plane;
+    float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)pair * plane;
     const int nsteps = (H + 1) / 2;
     // Each role runs its own loop; all three execute one barrier before the loop and two per step.
     if (role == 0)
