@@ -21,6 +21,7 @@ struct MapSrc {
     ptrdiff_t astride;   // row stride in floats
     ptrdiff_t bstride;
     int x0, y0;          // FUSED: position of the destination crop inside the canvas
+    int ox, oy;          // FUSED: canvas position of the first vector stored at `a` (0,0 for a whole canvas)
     int sign;            // FUSED: map = grid + sign * flow
 };
 
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void k_remap_u8(const uint8_t* __restrict__ sr
     if (x >= dw || y >= dh) return;
     float mx, my;
     if (FUSED) {
-        const float2 f = *(const float2*)(m.a + (ptrdiff_t)(m.y0 + y) * m.astride + 2 * (m.x0 + x));
+        const float2 f = *(const float2*)(m.a + (ptrdiff_t)(m.y0 + y - m.oy) * m.astride + 2 * (m.x0 + x - m.ox));
         mx = (float)((double)(m.x0 + x) + (double)m.sign * (double)f.x);
         my = (float)((double)(m.y0 + y) + (double)m.sign * (double)f.y);
     } else {
@@ -200,7 +201,7 @@ extern "C" int nsof_remap_linear_u8_dev(nsof_ctx* ctx, const uint8_t* d_src, ptr
     if (rc) return rc;
     if (map_x_stride_floats < dst_w || map_y_stride_floats < dst_w) return nsof_set_error(ctx, NSOF_EINVAL, "map stride");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
-    MapSrc m{d_map_x, d_map_y, map_x_stride_floats, map_y_stride_floats, 0, 0, 0};
+    MapSrc m{d_map_x, d_map_y, map_x_stride_floats, map_y_stride_floats, 0, 0, 0, 0, 0};
     return launch_remap<false>(ctx, channels, d_src, src_stride, src_w, src_h, m, dst_w, dst_h, border_mode,
                                border_value & 255, d_dst, dst_stride);
 }
@@ -221,7 +222,7 @@ extern "C" int nsof_predict_warp_u8_dev(nsof_ctx* ctx, const uint8_t* d_frame, p
     if (flow_stride_floats < 2 * (ptrdiff_t)width || (flow_stride_floats & 1))
         return nsof_set_error(ctx, NSOF_EINVAL, "flow stride");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
-    MapSrc m{d_flow, nullptr, flow_stride_floats, 0, x0, y0, sign};
+    MapSrc m{d_flow, nullptr, flow_stride_floats, 0, x0, y0, 0, 0, sign};
     // the destination is the same crop of the output frame
     return launch_remap<true>(ctx, channels, d_frame, frame_stride, width, height, m, x1 - x0, y1 - y0, border_mode, 0,
                               d_out + (ptrdiff_t)y0 * out_stride + (ptrdiff_t)x0 * channels, out_stride);
@@ -241,11 +242,15 @@ extern "C" int nsof_predict_warp_u8(nsof_ctx* ctx, const uint8_t* frame, ptrdiff
     if (frame_stride < (ptrdiff_t)width * channels || out_stride < (ptrdiff_t)width * channels ||
         flow_stride_bytes < (ptrdiff_t)rw * 8)
         return nsof_set_error(ctx, NSOF_EINVAL, "stride");
+    int rc;
+    if ((rc = check_remap_args(ctx, channels, width, height, (ptrdiff_t)width * channels, rw, rh,
+                               (ptrdiff_t)rw * channels, border_mode)))
+        return rc;
+    if (sign != 1 && sign != -1) return nsof_set_error(ctx, NSOF_EINVAL, "sign must be +1 or -1");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     const size_t rowb = (size_t)width * channels;
     const size_t szI = (rowb * height + 255) & ~(size_t)255, szF = ((size_t)rw * rh * 8 + 255) & ~(size_t)255;
     const size_t szO = ((size_t)rw * rh * channels + 255) & ~(size_t)255;
-    int rc;
     if ((rc = nsof_ws_reserve(ctx, &ctx->stage, &ctx->stage_bytes, szI + szF + szO))) return rc;
     if ((rc = nsof_hstage_reserve(ctx, szI + szF + szO))) return rc;
     uint8_t* hI = (uint8_t*)ctx->hstage;
@@ -261,12 +266,8 @@ extern "C" int nsof_predict_warp_u8(nsof_ctx* ctx, const uint8_t* frame, ptrdiff
     for (int y = 0; y < rh; y++)
         memcpy(hF + (size_t)y * rw * 2, (const char*)flow_crop + (ptrdiff_t)y * flow_stride_bytes, (size_t)rw * 8);
     NSOF_HIP(ctx, hipMemcpyAsync(dF, hF, (size_t)rw * rh * 8, hipMemcpyHostToDevice, ctx->stream));
-    // device-side flow is the crop alone: shift the canvas origin so that canvas (x0, y0) is its first element
-    MapSrc m{dF - ((ptrdiff_t)y0 * 2 * rw + 2 * (ptrdiff_t)x0), nullptr, 2 * (ptrdiff_t)rw, 0, x0, y0, sign};
-    if ((rc = check_remap_args(ctx, channels, width, height, (ptrdiff_t)rowb, rw, rh, (ptrdiff_t)rw * channels,
-                               border_mode)))
-        return rc;
-    if (sign != 1 && sign != -1) return nsof_set_error(ctx, NSOF_EINVAL, "sign must be +1 or -1");
+    // device-side flow is the crop alone: its first vector is canvas position (x0, y0)
+    MapSrc m{dF, nullptr, 2 * (ptrdiff_t)rw, 0, x0, y0, x0, y0, sign};
     if ((rc = launch_remap<true>(ctx, channels, dI, (ptrdiff_t)rowb, width, height, m, rw, rh, border_mode, 0, dO,
                                  (ptrdiff_t)rw * channels)))
         return rc;
