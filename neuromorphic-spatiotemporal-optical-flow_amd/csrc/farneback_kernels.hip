@@ -164,23 +164,27 @@ __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restric
 //     over RING / S steps),
 //   * column filter at the two sampled rows, then resize's 2x2 blend (all four weights are exactly 0.5).
 // Same operation order as the other prep kernels (row_filter / col_filter), so the output is bit-identical.
-template <int S, int KS>
+template <int S, int KS, int CW>
 __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                      ptrdiff_t img_stride, int W, int H, int wk, int hk, int seg_rows,
                                                      nsof_blur_taps t, float* __restrict__ out)
 {
-    constexpr int R = KS / 2, NPX = 16 / S, NC = 2 * NPX;
+    // CW = source columns per lane: 16 (one 16-B load per row) when W % 16 == 0, else 8 (W % 8 == 0, e.g. the
+    // 1080-wide portrait frames of the reference's grasp sequence)
+    constexpr int R = KS / 2, NPX = CW / S, NC = 2 * NPX;
     constexpr int RING = (KS + 1 + S - 1) / S * S, U = RING / S;
     constexpr int HB = (R + 3) / 4 * 4, HD = HB / 4;          // halo bytes / dwords per side
+    constexpr int WIN = HB + CW + HB;
+    static_assert(NPX >= 1, "lane narrower than one output pixel");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = blockIdx.x * 64 + lane;                      // 16-column group
+    const int T = blockIdx.x * 64 + lane;                      // CW-column group
     const int seg = blockIdx.y * 4 + wave;
     const int dy0 = seg * seg_rows;
     if (dy0 >= hk) return;                                     // wave-uniform
     const int dy1 = min(dy0 + seg_rows, hk);
-    const bool live = 16 * T < W;
-    const int x16 = live ? 16 * T : 0;
-    const bool edge_l = x16 == 0, edge_r = x16 + 16 >= W;
+    const bool live = CW * T < W;
+    const int xc0 = live ? CW * T : 0;
+    const bool edge_l = xc0 == 0, edge_r = xc0 + CW >= W;
     const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
     float* dst = out + (size_t)blockIdx.z * wk * hk;
     auto tk = [&](int j) { return t.k[j]; };                   // static index after unrolling
@@ -189,30 +193,40 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
 
     // row filter of (unreflected) source row r at this lane's sampled columns -> ring[slot]
     auto load_row = [&](int r, float (&dstrow)[NC]) {
-        const uint8_t* rowp = img + (ptrdiff_t)reflect101(r, H) * row_stride + x16;
-        const uint4 c = *reinterpret_cast<const uint4*>(rowp);
+        const uint8_t* rowp = img + (ptrdiff_t)reflect101(r, H) * row_stride + xc0;
+        unsigned cw[CW / 4];
+        if (CW == 16) {
+            const uint4 c = *reinterpret_cast<const uint4*>(rowp);
+            cw[0] = c.x; cw[1] = c.y; cw[(CW / 4 > 2) ? 2 : 0] = c.z; cw[(CW / 4 > 3) ? 3 : 0] = c.w;
+        } else {
+            const uint2 c = *reinterpret_cast<const uint2*>(rowp);
+            cw[0] = c.x; cw[1] = c.y;
+        }
         unsigned hl[HD], hr[HD];
         const uint8_t* lp = edge_l ? rowp : rowp - HB;          // edge lanes: any valid address, value unused
-        const uint8_t* rp = edge_r ? rowp : rowp + 16;
+        const uint8_t* rp = edge_r ? rowp : rowp + CW;
 #pragma unroll
         for (int d = 0; d < HD; d++) {
             hl[d] = reinterpret_cast<const unsigned*>(lp)[d];
             hr[d] = reinterpret_cast<const unsigned*>(rp)[d];
         }
-        const unsigned cw[4] = {c.x, c.y, c.z, c.w};
-        float fb[HB + 16 + HB];
-#pragma unroll
-        for (int b = 0; b < 16; b++) fb[HB + b] = (float)((cw[b >> 2] >> (8 * (b & 3))) & 0xffu);
+        float raw[WIN];   // window [xc0 - HB, xc0 + CW + HB) as loaded
 #pragma unroll
         for (int b = 0; b < HB; b++) {
-            // left halo byte b is column x16 - HB + b; at the image edge it reflects to column HB - b (own bytes)
-            const float own_l = fb[HB + (HB - b)];
-            const float ld_l = (float)((hl[b >> 2] >> (8 * (b & 3))) & 0xffu);
-            fb[b] = edge_l ? own_l : ld_l;
-            // right halo byte b is column x16 + 16 + b; at the edge (x16 + 16 == W) it reflects to W - 2 - b
-            const float own_r = fb[HB + 14 - b];
-            const float ld_r = (float)((hr[b >> 2] >> (8 * (b & 3))) & 0xffu);
-            fb[HB + 16 + b] = edge_r ? own_r : ld_r;
+            raw[b] = (float)((hl[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            raw[HB + CW + b] = (float)((hr[b >> 2] >> (8 * (b & 3))) & 0xffu);
+        }
+#pragma unroll
+        for (int b = 0; b < CW; b++) raw[HB + b] = (float)((cw[b >> 2] >> (8 * (b & 3))) & 0xffu);
+        float fb[WIN];
+#pragma unroll
+        for (int b = 0; b < CW; b++) fb[HB + b] = raw[HB + b];
+#pragma unroll
+        for (int b = 0; b < HB; b++) {
+            // left halo byte b is column xc0 - HB + b; at the image edge (xc0 == 0) it reflects to column HB - b
+            fb[b] = edge_l ? raw[HB + (HB - b)] : raw[b];
+            // right halo byte b is column xc0 + CW + b; at the edge (xc0 + CW == W) it reflects to column W - 2 - b
+            fb[HB + CW + b] = edge_r ? raw[HB + CW - 2 - b] : raw[HB + CW + b];
         }
 #pragma unroll
         for (int n = 0; n < NC; n++) {
@@ -250,12 +264,14 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
                 }
                 float* op = dst + (size_t)dy * wk + NPX * T;
                 if (NPX == 8) {
-                    nsof_store_stream4(op, o[0], o[1], o[2], o[3]);
+                    nsof_store_stream4(op, o[0], o[1 % NPX], o[2 % NPX], o[3 % NPX]);
                     nsof_store_stream4(op + 4, o[4 % NPX], o[5 % NPX], o[6 % NPX], o[7 % NPX]);
                 } else if (NPX == 4) {
-                    nsof_store_stream4(op, o[0], o[1], o[2 % NPX], o[3 % NPX]);
+                    nsof_store_stream4(op, o[0], o[1 % NPX], o[2 % NPX], o[3 % NPX]);
+                } else if (NPX == 2) {
+                    nsof_store_stream2(op, o[0], o[1 % NPX]);
                 } else {
-                    nsof_store_stream2(op, o[0], o[1]);
+                    __builtin_nontemporal_store(o[0], op);
                 }
             }
         }
@@ -1129,8 +1145,11 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
                                (taps.ksize == 3 || taps.ksize == 5);   // larger kernels: registers run out
         // exact decimation by 2 / 4 / 8 with the kernel sizes the pyr_scale 0.5 pyramid produces
         const int S = W / wk;
-        const bool decim_ok = W == S * wk && H == S * hk && (W & 15) == 0 && (row_stride & 15) == 0 &&
-                              (img_stride & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+        static const bool force8 = getenv("NSOF_DECIM_CW8") != nullptr;   // A/B: 8-column lanes everywhere
+        const int CWL = ((W & 15) == 0 && !force8) ? 16 : 8;   // source columns per lane
+        const bool decim_ok = S >= 2 && W == S * wk && H == S * hk && (W % CWL) == 0 && W >= 64 &&
+                              (row_stride % CWL) == 0 && (img_stride % CWL) == 0 &&
+                              (reinterpret_cast<uintptr_t>(src) % CWL) == 0 &&
                               ((S == 2 && taps.ksize == 3) || (S == 4 && taps.ksize == 9) ||
                                (S == 8 && taps.ksize == 19)) &&
                               H > taps.ksize && getenv("NSOF_PREP_NODECIM") == nullptr;
@@ -1140,16 +1159,20 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
             int seg_rows = S == 2 ? 32 : (S == 4 ? 24 : 15);
             seg_rows = (seg_rows + U - 1) / U * U;
             const int nseg = (hk + seg_rows - 1) / seg_rows;
-            dim3 grid((W / 16 + 63) / 64, (nseg + 3) / 4, n_img);
-            if (S == 2)
-                hipLaunchKernelGGL((k_prep_decim<2, 3>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride,
-                                   W, H, wk, hk, seg_rows, taps, out);
-            else if (S == 4)
-                hipLaunchKernelGGL((k_prep_decim<4, 9>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride,
-                                   W, H, wk, hk, seg_rows, taps, out);
-            else
-                hipLaunchKernelGGL((k_prep_decim<8, 19>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride,
-                                   W, H, wk, hk, seg_rows, taps, out);
+            dim3 grid((W / CWL + 63) / 64, (nseg + 3) / 4, n_img);
+#define NSOF_DECIM(SS, KK, CC)                                                                                      \
+    hipLaunchKernelGGL((k_prep_decim<SS, KK, CC>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, \
+                       H, wk, hk, seg_rows, taps, out)
+            if (CWL == 16) {
+                if (S == 2) NSOF_DECIM(2, 3, 16);
+                else if (S == 4) NSOF_DECIM(4, 9, 16);
+                else NSOF_DECIM(8, 19, 16);
+            } else {
+                if (S == 2) NSOF_DECIM(2, 3, 8);
+                else if (S == 4) NSOF_DECIM(4, 9, 8);
+                else NSOF_DECIM(8, 19, 8);
+            }
+#undef NSOF_DECIM
         } else if (direct_ok) {
             dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
 #define NSOF_PREP_DIRECT(KS)                                                                                       \

@@ -68,7 +68,8 @@ def test_pyr_level_bit_exact(ctx, oracle, torch_dev, frames, pyr_scale, level, s
 
 
 @pytest.mark.parametrize("level", [1, 2, 3])
-@pytest.mark.parametrize("shape", [(272, 480), (24, 16), (184, 1040), (1080, 1920)])
+@pytest.mark.parametrize("shape", [(272, 480), (24, 16), (184, 1040), (1080, 1920), (1920, 1080), (200, 72),
+                                   (96, 64)])
 def test_pyr_level_exact_decimation_path(ctx, oracle, torch_dev, level, shape):
     """Dense, 16-byte aligned frames whose size divides by 2^level take the decimating walker kernel
     (k_prep_decim); same bits as the oracle, and as the generic kernels (NSOF_PREP_NODECIM)."""
