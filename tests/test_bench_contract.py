@@ -1,0 +1,35 @@
+"""bench.py prints ONE JSON line with the fields the driver and the judge read (task statement, sections 4 and
+"How to work"): metric/value/unit/n_gpus/steps/warmup/ms_per_step/higher_is_better/scaling/vs_baseline/dtype/data/
+config.workload plus the roofline and cpu_baseline objects.  Small batch so the test takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.gpu
+def test_bench_json_contract():
+    env = dict(os.environ, NSOF_SKIP_BUILD="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "8", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "1"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert d["max_abs_epe_vs_oracle"] <= d["epe_tolerance"]
