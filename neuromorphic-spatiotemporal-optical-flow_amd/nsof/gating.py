@@ -32,6 +32,9 @@ class GatingConfig:
     FLAG: int = 2                     # 1 = one flow call per component, 2 = one call on the union box
     farneback_params: FarnebackParams = PARAMS_A
     bug_compatible: bool = True       # the scripts gate on slice OFFSET+i (memimg2 := memimg1, seg.py:435)
+    # dtype of the frame-sized flow canvas: float64 as in the reference (np.zeros((h, w, 2)), seg.py:213); float32
+    # holds the same values (the flow IS float32) and halves the host-side zeroing / negation cost per pair
+    canvas_dtype: type = np.float64
     # timing lists the reference keeps at module level (optical_flow_seg.py:51-59)
     mem_opticalflow_times: list = field(default_factory=list)
     mem_cal_times: list = field(default_factory=list)
@@ -205,7 +208,7 @@ def opticalFlow3D(memimg1, memimg2, rgbimg1, rgbimg2, pixel_width, pixel_height,
     cfg = cfg or GatingConfig()
     t0 = time.time()
     h, w = rgbimg1.shape[:2]
-    flow = np.zeros((h, w, 2))
+    flow = np.zeros((h, w, 2), cfg.canvas_dtype)
     transition_pic = np.zeros((int(h / pixel_height), int(w / pixel_width)))
     transition_pic = update_transition_pic(memimg2, transition_pic, cfg.THRES).astype(np.uint8)
     num_labels, _, stats, _ = connectedComponentsWithStats(transition_pic, connectivity=cfg.CONNECT)

@@ -207,3 +207,22 @@ def test_segmentation_harness_gpu_equals_oracle_backends(nsof_lib, oracle):
     assert len(res[0][0]) == 2
     assert res[0][1:] == res[1][1:]                                   # mean accuracies identical
     assert [r[8:11] for r in res[0][0]] == [r[8:11] for r in res[1][0]]   # per-pair accuracies and region shares
+
+
+def test_float32_canvas_option(nsof_lib, maps, oracle):
+    """cfg.canvas_dtype=float32: same values as the reference's float64 canvas."""
+    from nsof import synth
+    _, slices = maps["grasp"]
+    cur = slices[1]
+    hm, wm = cur.shape
+    h, w = hm * 8, wm * 8
+    a, b = synth.make_pair(5, h, w)
+    mem = nsof_lib.current_to_gray(cur)
+    far = lambda p, q, _f, **kw: oracle.farneback(p, q, **kw)  # noqa: E731
+    out = []
+    for dt in (np.float64, np.float32):
+        cfg = nsof_lib.dataset_config("grasp", MEMSIZE=8, EXTEND_HEIGHT_UPPER=2, EXTEND_HEIGHT_LOWER=2,
+                                      EXTEND_WIDTH_LEFT=2, EXTEND_WIDTH_RIGHT=2, canvas_dtype=dt)
+        out.append(nsof_lib.opticalFlow3D(mem, mem, a, b, 8, 8, cfg, flow_fn=far)[0])
+    assert out[0].dtype == np.float64 and out[1].dtype == np.float32 and np.array_equal(out[0], out[1])
+    assert np.abs(out[0]).max() > 0
