@@ -184,3 +184,43 @@ def test_bincount_2d_matches_reference_and_numpy(nsof_lib):
     assert nsof_lib.bincount_2d(np.array([], int), np.array([], int), 4, 5).sum() == 0
     with pytest.raises(nsof_lib.NsofError):
         nsof_lib.bincount_2d(np.array([5]), np.array([0]), 4, 5)
+
+
+@pytest.mark.gpu
+def test_full_size_sensor_properties(nsof_lib, ctx, oracle):
+    """BASELINE config 5 size (3840x2160): sparse path == forced-dense path bit for bit; untouched pixels keep the
+    initial state exactly; a leaking silent voltage (outside the dead zone: every pixel changes every slice) matches
+    the oracle on the whole array; chunked == one-shot."""
+    from nsof import synth
+    from nsof.accumulator import Accumulator, slice_index_array
+    H, W = 2160, 3840
+    x, y, p, t = synth.make_events(5, W, H, 40_000, 40_000, box=(400, 300))
+    idx = slice_index_array(t, 1000)
+    res = {}
+    for dense in (False, True):
+        acc = Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=ctx, dense=dense)
+        acc.step(x, y, p, t, idx, snap_every=0)
+        res[dense] = acc.w(0)
+        acc.close()
+    assert np.array_equal(res[False], res[True])
+    touched = np.zeros((H, W), bool)
+    n_in = int(idx[-1])
+    touched[y[:n_in], x[:n_in]] = True
+    assert np.all(res[False][~touched] == np.float32(0.5)) and np.all(res[False][touched] > 0.5)
+    # leak: silent_v = 0.4 > von -> the whole array decays every slice (dense math on all 8.3 Mpx)
+    acc = Accumulator(H, W, 1, "split", -6.0, 0.4, ctx=ctx)
+    k = 8                                                    # slices, one shot vs two chunks
+    acc.step(x, y, p, t, idx[:k + 1], snap_every=0)
+    one = acc.w(0)
+    acc.reset()
+    acc.step(x, y, p, t, idx[:4], snap_every=0)
+    acc.step(x, y, p, t, idx[3:k + 1], snap_every=0)
+    two = acc.w(0)
+    acc.close()
+    assert np.array_equal(one, two)
+    w = np.full((H, W), 0.5, np.float32)
+    for s in range(k):
+        V = np.full((H, W), 0.4, np.float32)
+        V[y[idx[s]:idx[s + 1]], x[idx[s]:idx[s + 1]]] = -6.0
+        w = oracle.accum_update_state(w, V)
+    assert np.abs(one - w).max() <= W_ATOL
