@@ -35,10 +35,56 @@ constexpr long long REFRACTORY_US = 800;
 constexpr float WINI = 0.5f;
 constexpr int MAX_GROUP = 32;
 
+// x ** b for the float32 state update, evaluated in double and rounded once (NumPy's float32 power is accurate to
+// about an ulp; this is correctly rounded except within ~1e-13 of a rounding boundary).  The library log()/exp() spend
+// most of their ~150 double-precision instructions on ranges and special cases that cannot occur here
+// (x = 1 - w*s lies in [0.2, 1] for a state in [0, 1]); the series below need ~55 and are accurate to 4e-14:
+//   log: x = m * 2^e with m in [sqrt(1/2), sqrt(2)), z = (m-1)/(m+1), log m = 2z(1 + z^2/3 + ... + z^14/15)
+//   exp: y = k ln2 + r with |r| <= ln2/2, exp r = sum r^n/n! (n <= 13), scaled by 2^k
+__device__ __forceinline__ double log_unit_range(double x)
+{
+    int e;
+    double m = frexp(x, &e);                       // m in [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    const double z = (m - 1.0) / (m + 1.0), w = z * z;
+    double p = 1.0 / 15.0;
+    p = fma(p, w, 1.0 / 13.0);
+    p = fma(p, w, 1.0 / 11.0);
+    p = fma(p, w, 1.0 / 9.0);
+    p = fma(p, w, 1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0);
+    p = fma(p, w, 1.0 / 3.0);
+    p = fma(p, w, 1.0);
+    const double de = (double)e;
+    return fma(de, 0x1.62e42feep-1, fma(de, 0x1.a39ef35793c76p-33, 2.0 * z * p));   // e * ln2 in two parts
+}
+__device__ __forceinline__ double exp_small(double y)   // |y| < 700
+{
+    const double k = rint(y * 1.4426950408889634074);
+    const double r = fma(-k, 0x1.a39ef35793c76p-33, fma(-k, 0x1.62e42feep-1, y));
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
 __device__ __forceinline__ float pow_f32(float x, float b)
 {
-    // x > 0 on every path that reaches here (1 - w*s with w in [0,1], s < 1)
-    return (float)exp((double)b * log((double)x));
+    // a state outside [0,1] handed to the element-wise entry point can make x <= 0: NumPy gives nan for a negative
+    // base, 0 or inf for a zero base
+    if (!(x > 0.f)) return x < 0.f ? __builtin_nanf("") : (x == 0.f ? (b > 0.f ? 0.f : __builtin_inff()) : x);
+    if (x > 2.f || x < 1e-3f) return (float)exp((double)b * log((double)x));   // far outside the model's range
+    return (float)exp_small((double)b * log_unit_range((double)x));
 }
 
 __device__ __forceinline__ float update_one(float w, float V)
