@@ -103,6 +103,26 @@ __device__ __forceinline__ float update_one(float w, float V)
     return wn < 0.f ? 0.f : (wn > 1.f ? 1.f : wn);
 }
 
+// A slice's voltage is one of two values per run (active / silent), so everything of update_one that depends on V
+// alone is evaluated once: the branch taken, k * (V/v0 - 1) (the first product of "k * a * b", same rounding), and the
+// (s, b) pair of the power term.  The per-slice step is then branch-free: one pow, two multiplies, one add, the clip.
+struct Drive {
+    float ka, s, b;   // ka = 0 in the dead zone: dw = 0 * pow(..) = 0, w unchanged, as in update_one
+};
+__device__ __forceinline__ Drive drive_of(float V)
+{
+    Drive d;
+    if (V < VOFF) { d.ka = KOFF * (V / VOFF - 1.f); d.s = SOFF; d.b = BOFF; }
+    else if (V > VON) { d.ka = KON * (V / VON - 1.f); d.s = SON; d.b = BON; }
+    else { d.ka = 0.f; d.s = SOFF; d.b = BOFF; }
+    return d;
+}
+__device__ __forceinline__ float update_drive(float w, const Drive& d)
+{
+    const float wn = w + (d.ka * pow_f32(1.f - w * d.s, d.b)) * DT;
+    return wn < 0.f ? 0.f : (wn > 1.f ? 1.f : wn);
+}
+
 __device__ __forceinline__ float resistance_one(float w, float neg_lam)
 {
     const float e = (float)exp((double)(neg_lam * (1.0f - w)));
@@ -184,8 +204,9 @@ __global__ __launch_bounds__(256) void k_update_sparse(float* __restrict__ w, un
         unsigned m = mask[pix];
         mask[pix] = 0;
         float ww = w[pix];
+        const Drive da = drive_of(v_act);
         for (int s = 0; s < n_sl; s++, m >>= 1)
-            if (m & 1u) ww = update_one(ww, v_act);
+            if (m & 1u) ww = update_drive(ww, da);
         w[pix] = ww;
     }
 }
@@ -199,11 +220,19 @@ template <bool SIL_NOOP>
 __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, unsigned* __restrict__ mask, size_t n4,
                                                        size_t n, int n_sl, float v_act, float v_sil)
 {
+    const Drive da = drive_of(v_act), ds = drive_of(v_sil);
     auto replay = [&](float ww, unsigned m) {
         if (SIL_NOOP) {
-            for (; m; m &= m - 1) ww = update_one(ww, v_act);
+            for (; m; m &= m - 1) ww = update_drive(ww, da);
         } else {
-            for (int s = 0; s < n_sl; s++) ww = update_one(ww, (m >> s) & 1u ? v_act : v_sil);
+            for (int s = 0; s < n_sl; s++) {
+                const bool act = (m >> s) & 1u;
+                Drive d;
+                d.ka = act ? da.ka : ds.ka;
+                d.s = act ? da.s : ds.s;
+                d.b = act ? da.b : ds.b;
+                ww = update_drive(ww, d);
+            }
         }
         return ww;
     };
