@@ -7,7 +7,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "neuromorphic-spatiotemporal-optical-flow_amd")]
 os.environ.setdefault("NSOF_SKIP_BUILD", "1")
-import numpy as np  # noqa: E402
 import nsof  # noqa: E402
 from nsof import synth  # noqa: E402
 from nsof.farneback import PARAMS_A, PARAMS_B  # noqa: E402
