@@ -88,6 +88,38 @@ int nsof_farneback_u8_sequence_dev(nsof_ctx* ctx, int n_frames, const uint8_t* d
                                    double pyr_scale, int levels, int winsize, int iterations,
                                    int poly_n, double poly_sigma, int flags);
 
+/* One frame pair of a shape-heterogeneous batch: what ONE call of cv2.calcOpticalFlowFarneback(prev_region,
+ * next_region, None, **farneback_params) receives and returns in the gated path -- optical_flow_seg.py:129-164
+ * (one crop per connected component), :186-203 (the union box), :492-496 (the full frame) -- as plain pointers.
+ * flow_stride in bytes (a multiple of 8): a view flow_canvas[y0:y1, x0:x1] of a frame-sized float32 (H,W,2)
+ * canvas is written in place, which is the paste of :162 / :204. */
+typedef struct nsof_pair_desc {
+    const uint8_t* prev;
+    ptrdiff_t prev_stride;
+    const uint8_t* next;
+    ptrdiff_t next_stride;
+    int width, height;
+    float* flow;
+    ptrdiff_t flow_stride;
+} nsof_pair_desc;
+
+/* n_pairs pairs of ANY shapes, one parameter set, HOST memory (pointers are not retained; blocks until every flow
+ * field is in host memory).  All pairs share every kernel launch (a work list per pyramid level), so many small ROI
+ * calls cost about as much as one; the list is processed in chunks whose upload, compute and download overlap on
+ * three streams.  Buffers from nsof_host_alloc() (page-locked) are copied to/from directly, other memory goes
+ * through an internal pinned staging buffer.  Result per pair == nsof_farneback_u8 of that pair, bit for bit. */
+int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs,
+                            double pyr_scale, int levels, int winsize, int iterations,
+                            int poly_n, double poly_sigma, int flags);
+/* Device-resident twin: `pairs` is a HOST array whose prev/next/flow are DEVICE addresses (e.g. crops of frames
+ * and of flow canvases already in HBM).  Asynchronous on the context's stream. */
+int nsof_farneback_u8_batch_desc_dev(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs,
+                                     double pyr_scale, int levels, int winsize, int iterations,
+                                     int poly_n, double poly_sigma, int flags);
+/* Page-locked host memory for frames / flow fields handed to nsof_farneback_u8_batch (NULL on failure). */
+void* nsof_host_alloc(size_t bytes);
+void nsof_host_free(void* p);
+
 /* Geometry helpers (pure host arithmetic, usable without a device: ctx may be NULL). */
 int nsof_farneback_effective_levels(int width, int height, double pyr_scale, int levels);
 int nsof_farneback_level_size(int width, int height, double pyr_scale, int level,

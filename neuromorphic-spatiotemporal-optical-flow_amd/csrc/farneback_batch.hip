@@ -1,0 +1,456 @@
+// Shape-heterogeneous Farneback batches: the work-list driver and the pipelined host entry point.
+//
+// The reference's gated path calls cv2.calcOpticalFlowFarneback once per ROI, on crops whose shape changes from
+// call to call (/root/reference/optical_flow_seg.py:129-164 per connected component, :186-203 union box), and its
+// evaluation loop mixes those with full-frame calls (:492-496).  A crop of 520x200 px cannot fill 256 CUs -- the
+// fused iteration walks its rows serially in 3 workgroups -- so here MANY such calls share every launch:
+//
+//   * nsof_farneback_u8_batch_desc_dev: per level one launch per stage over a device table of work items
+//     (nsof_het_item, nsof_internal.h); an item takes part from its own coarsest level on; the last iteration of
+//     level 0 writes straight into the caller's (strided) flow field, so an ROI result lands in the frame-sized
+//     canvas without a paste.  Arithmetic per item is that of the per-call path, bit for bit.
+//   * nsof_farneback_u8_batch: the same for HOST memory, as a three-stage pipeline over chunks of the list
+//     (upload of chunk c+1 and download of chunk c-1 on their own streams while chunk c computes).
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "nsof_internal.h"
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Params {
+    double pyr_scale;
+    int levels, winsize, iterations, poly_n;
+    double poly_sigma;
+    int flags;
+};
+
+int validate_desc(nsof_ctx* ctx, int i, const nsof_pair_desc& d, const Params& p)
+{
+    if (!d.prev || !d.next || !d.flow) return nsof_set_error(ctx, NSOF_EINVAL, "pair %d: null pointer", i);
+    int rc = nsof_check_farneback_params(ctx, d.width, d.height, p.pyr_scale, p.levels, p.winsize, p.iterations, p.poly_n,
+                                         p.flags);
+    if (rc) return rc;
+    if (d.prev_stride < d.width || d.next_stride < d.width)
+        return nsof_set_error(ctx, NSOF_EINVAL, "pair %d: row stride < width", i);
+    if (d.flow_stride < (ptrdiff_t)d.width * 8 || (d.flow_stride & 7) || (reinterpret_cast<uintptr_t>(d.flow) & 7))
+        return nsof_set_error(ctx, NSOF_EINVAL, "pair %d: flow stride %lld / pointer must be multiples of 8 bytes and "
+                              "the stride >= width*8", i, (long long)d.flow_stride);
+    return NSOF_OK;
+}
+
+// One item through the uniform-shape driver (shapes or parameters the work-list kernels do not cover): frames are
+// packed densely, the result is copied into the caller's strided field.
+int fallback_item(nsof_ctx* ctx, const nsof_pair_desc& d, const Params& p)
+{
+    const size_t n0 = (size_t)d.width * d.height;
+    const size_t szU = align_up(n0, 256), szF = align_up(n0 * 8, 256);
+    int rc = nsof_ws_reserve(ctx, &ctx->stage, &ctx->stage_bytes, 2 * szU + szF);
+    if (rc) return rc;
+    uint8_t* dP = (uint8_t*)ctx->stage;
+    uint8_t* dN = dP + szU;
+    float* dF = (float*)(dN + szU);
+    NSOF_HIP(ctx, hipMemcpy2DAsync(dP, d.width, d.prev, d.prev_stride, d.width, d.height, hipMemcpyDeviceToDevice, ctx->stream));
+    NSOF_HIP(ctx, hipMemcpy2DAsync(dN, d.width, d.next, d.next_stride, d.width, d.height, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = nsof_farneback_core(ctx, false, 1, dP, dN, d.width, (ptrdiff_t)szU, d.width, d.height, dF, p.pyr_scale, p.levels,
+                             p.winsize, p.iterations, p.poly_n, p.poly_sigma, p.flags);
+    if (rc) return rc;
+    NSOF_HIP(ctx, hipMemcpy2DAsync(d.flow, d.flow_stride, dF, (size_t)d.width * 8, (size_t)d.width * 8, d.height,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return NSOF_OK;
+}
+
+// The work-list driver.  descs: HOST array whose pointers are DEVICE addresses.
+int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
+{
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; i++)
+        if (int rc = validate_desc(ctx, i, descs[i], p)) return rc;
+
+    // Items the work-list kernels cover: fused iteration available (window 2..15, >= 1 iteration, at least 2x2 px).
+    const bool het_params = p.iterations >= 1 && p.winsize / 2 >= 1 && p.winsize / 2 <= 7;
+    std::vector<int> het, rest;
+    for (int i = 0; i < n; i++)
+        (het_params && nsof_iterate_supported(p.winsize, descs[i].width, descs[i].height) ? het : rest).push_back(i);
+
+    if (!het.empty()) {
+        const int nh = (int)het.size();
+        nsof_poly_taps ptaps;
+        int rc = nsof_host_poly_taps(p.poly_n, p.poly_sigma, &ptaps);
+        if (rc) return nsof_set_error(ctx, rc, "poly taps");
+        // per-item level count; tables per level (items without that level are left out)
+        std::vector<int> Li(nh);
+        int Lmax = 0;
+        for (int j = 0; j < nh; j++) {
+            Li[j] = nsof_farneback_effective_levels(descs[het[j]].width, descs[het[j]].height, p.pyr_scale, p.levels);
+            Lmax = std::max(Lmax, Li[j]);
+        }
+        // two table slots used alternately: the upload of call c may still be queued when call c+1 builds its tables
+        const size_t tab_bytes = align_up((size_t)(Lmax + 1) * nh * sizeof(nsof_het_item), 256);
+        if (ctx->het_bytes < 2 * tab_bytes) {
+            NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->het_h) hipHostFree(ctx->het_h);
+            if (ctx->het_d) hipFree(ctx->het_d);
+            ctx->het_h = ctx->het_d = nullptr;
+            ctx->het_bytes = 0;
+            const size_t cap = align_up(tab_bytes * 4, 4096);
+            if (hipHostMalloc(&ctx->het_h, cap, hipHostMallocDefault) != hipSuccess || hipMalloc(&ctx->het_d, cap) != hipSuccess)
+                return nsof_set_error(ctx, NSOF_ENOMEM, "work-list tables (%zu bytes)", cap);
+            ctx->het_bytes = cap;
+        }
+        const int slot = ctx->het_flip;
+        ctx->het_flip ^= 1;
+        if (!ctx->het_ev[slot]) NSOF_HIP(ctx, hipEventCreateWithFlags(&ctx->het_ev[slot], hipEventDisableTiming));
+        else NSOF_HIP(ctx, hipEventSynchronize(ctx->het_ev[slot]));   // this slot's previous upload has left the pinned copy
+        const size_t slot_off = (size_t)slot * (ctx->het_bytes / 2);
+        nsof_het_item* tabs = (nsof_het_item*)((char*)ctx->het_h + slot_off);
+        const nsof_het_item* d_tabs = (const nsof_het_item*)((char*)ctx->het_d + slot_off);
+
+        // Build the tables, coarsest level first in memory order k = 0..Lmax (table k at tabs + k*nh).
+        std::vector<int> cnt(Lmax + 1, 0);
+        std::vector<unsigned long long> offF_prev(nh, 0);   // the item's flow offset at the next coarser level
+        size_t maxI = 0, maxR = 0, maxF = 0;
+        std::vector<int> max_w(Lmax + 1, 0), max_h(Lmax + 1, 0);
+        for (int k = Lmax; k >= 0; k--) {
+            unsigned long long oI = 0, oR = 0, oF = 0;
+            nsof_het_item* t = tabs + (size_t)k * nh;
+            for (int j = 0; j < nh; j++) {
+                if (Li[j] < k) continue;
+                const nsof_pair_desc& d = descs[het[j]];
+                nsof_het_item it;
+                memset(&it, 0, sizeof(it));
+                it.src[0] = d.prev; it.src[1] = d.next;
+                it.src_stride[0] = d.prev_stride; it.src_stride[1] = d.next_stride;
+                it.out = d.flow;
+                it.out_pitch = d.flow_stride / 8;
+                it.W = d.width; it.H = d.height;
+                nsof_farneback_level_size(d.width, d.height, p.pyr_scale, k, &it.wk, &it.hk, nullptr, nullptr);
+                if (k < Li[j]) nsof_farneback_level_size(d.width, d.height, p.pyr_scale, k + 1, &it.pw, &it.ph, nullptr, nullptr);
+                const unsigned long long nk = (unsigned long long)it.wk * it.hk;
+                it.offI = oI; it.offR = oR; it.offF = oF; it.offFc = offF_prev[j];
+                oI += align_up(2 * nk, 64); oR += align_up(10 * nk, 64); oF += align_up(nk, 32);
+                offF_prev[j] = it.offF;
+                const bool vec = (d.width & 3) == 0 && d.width >= 8 && (d.prev_stride & 3) == 0 && (d.next_stride & 3) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(d.prev) & 3) == 0 && (reinterpret_cast<uintptr_t>(d.next) & 3) == 0;
+                it.flags = vec ? NSOF_HET_VEC0 : 0;
+                max_w[k] = std::max(max_w[k], it.wk);
+                max_h[k] = std::max(max_h[k], it.hk);
+                t[cnt[k]++] = it;
+            }
+            maxI = std::max(maxI, (size_t)oI); maxR = std::max(maxR, (size_t)oR); maxF = std::max(maxF, (size_t)oF);
+        }
+        NSOF_HIP(ctx, hipMemcpyAsync((void*)d_tabs, tabs, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipEventRecord(ctx->het_ev[slot], ctx->stream));
+
+        // workspace: level images, expansions, two flow buffers (every level uses their leading part)
+        const size_t szI = align_up(maxI * 4, 256), szR = align_up(maxR * 4, 256), szF = align_up(maxF * 8, 256);
+        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + 2 * szF))) return rc;
+        char* base = (char*)ctx->ws;
+        float* dI = (float*)base;
+        float* dR = (float*)(base + szI);
+        float* fb[2] = {(float*)(base + szI + szR), (float*)(base + szI + szR + szF)};
+        int cur = 0;
+        for (int k = Lmax; k >= 0; k--) {
+            int wk, hk, ks;
+            double sg;
+            nsof_farneback_level_size(64, 64, p.pyr_scale, k, &wk, &hk, &ks, &sg);   // blur taps depend on k only
+            nsof_blur_taps btaps;
+            if ((rc = nsof_host_blur_taps(ks, sg, &btaps)))
+                return nsof_set_error(ctx, rc, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
+            const nsof_het_item* dt = d_tabs + (size_t)k * nh;
+            const nsof_het_item* ht = tabs + (size_t)k * nh;
+            const int nk_items = cnt[k];
+            // incoming flow of the level: resample of the coarser level's field (zero for items that start here)
+            if ((rc = nsof_launch_flow_upsample_het(ctx, nk_items, dt, max_w[k], max_h[k], fb[cur], fb[cur ^ 1],
+                                                    (float)(1. / p.pyr_scale))))
+                return rc;
+            cur ^= 1;
+            if ((rc = nsof_launch_prep_het(ctx, nk_items, dt, ht, k == 0, btaps, dI))) return rc;
+            if ((rc = nsof_launch_polyexp_het(ctx, nk_items, dt, max_w[k], max_h[k], ptaps, dI, dR))) return rc;
+            for (int it = 0; it < p.iterations; it++) {
+                const bool final = k == 0 && it == p.iterations - 1;
+                if ((rc = nsof_launch_iterate_het(ctx, nk_items, dt, max_w[k], dR, fb[cur], fb[cur ^ 1], final, p.winsize)))
+                    return rc;
+                cur ^= 1;
+            }
+        }
+    }
+    for (int i : rest)
+        if (int rc = fallback_item(ctx, descs[i], p)) return rc;
+    return NSOF_OK;
+}
+
+// ---- pipelined host entry ---------------------------------------------------------------------------------------
+void parallel_rows(size_t n_tasks, const std::function<void(size_t)>& fn)
+{
+    static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, hw), n_tasks);
+    if (nt <= 1) {
+        for (size_t i = 0; i < n_tasks; i++) fn(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            for (size_t i = t; i < n_tasks; i += nt) fn(i);
+        });
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+struct nsof_pipe {
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    struct Slot {
+        void* d_in = nullptr;  size_t d_in_bytes = 0;
+        void* d_out = nullptr; size_t d_out_bytes = 0;
+        void* h_in = nullptr;  size_t h_in_bytes = 0;
+        void* h_out = nullptr; size_t h_out_bytes = 0;
+        hipEvent_t in_done = nullptr, compute_done = nullptr, out_done = nullptr;
+    } slot[2];
+};
+
+void nsof_pipe_destroy(nsof_ctx* ctx)
+{
+    nsof_pipe* p = ctx->pipe;
+    if (!p) return;
+    for (auto& s : p->slot) {
+        if (s.d_in) hipFree(s.d_in);
+        if (s.d_out) hipFree(s.d_out);
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        if (s.in_done) hipEventDestroy(s.in_done);
+        if (s.compute_done) hipEventDestroy(s.compute_done);
+        if (s.out_done) hipEventDestroy(s.out_done);
+    }
+    if (p->s_in) hipStreamDestroy(p->s_in);
+    if (p->s_out) hipStreamDestroy(p->s_out);
+    delete p;
+    ctx->pipe = nullptr;
+}
+
+namespace {
+
+int pipe_get(nsof_ctx* ctx, nsof_pipe** out)
+{
+    if (!ctx->pipe) {
+        nsof_pipe* p = new (std::nothrow) nsof_pipe();
+        if (!p) return nsof_set_error(ctx, NSOF_ENOMEM, "out of host memory");
+        ctx->pipe = p;
+        NSOF_HIP(ctx, hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+        NSOF_HIP(ctx, hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+        for (auto& s : p->slot) {
+            NSOF_HIP(ctx, hipEventCreateWithFlags(&s.in_done, hipEventDisableTiming));
+            NSOF_HIP(ctx, hipEventCreateWithFlags(&s.compute_done, hipEventDisableTiming));
+            NSOF_HIP(ctx, hipEventCreateWithFlags(&s.out_done, hipEventDisableTiming));
+        }
+    }
+    *out = ctx->pipe;
+    return NSOF_OK;
+}
+
+int grow_dev(nsof_ctx* ctx, void** buf, size_t* cur, size_t need)
+{
+    if (*cur >= need) return NSOF_OK;
+    if (*buf) NSOF_HIP(ctx, hipFree(*buf));
+    *buf = nullptr; *cur = 0;
+    if (hipMalloc(buf, need) != hipSuccess) { *buf = nullptr; return nsof_set_error(ctx, NSOF_ENOMEM, "hipMalloc(%zu)", need); }
+    *cur = need;
+    return NSOF_OK;
+}
+int grow_host(nsof_ctx* ctx, void** buf, size_t* cur, size_t need)
+{
+    if (*cur >= need) return NSOF_OK;
+    if (*buf) NSOF_HIP(ctx, hipHostFree(*buf));
+    *buf = nullptr; *cur = 0;
+    if (hipHostMalloc(buf, need, hipHostMallocDefault) != hipSuccess) { *buf = nullptr; return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu)", need); }
+    *cur = need;
+    return NSOF_OK;
+}
+
+// Pinned (page-locked, HIP-registered) host memory can be the source / target of an asynchronous copy directly.
+bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // not a HIP allocation: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+struct Chunk {
+    int lo, hi;                       // items [lo, hi)
+    std::vector<size_t> in_off[2];    // byte offsets of the packed frames in the slot's input buffer
+    std::vector<size_t> out_off;      // byte offsets of the dense flow fields in the slot's output buffer
+    size_t in_bytes = 0, out_bytes = 0;
+};
+
+}  // namespace
+
+extern "C" int nsof_farneback_u8_batch_desc_dev(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs, double pyr_scale,
+                                                int levels, int winsize, int iterations, int poly_n, double poly_sigma,
+                                                int flags)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (n_pairs < 0 || (n_pairs > 0 && !pairs)) return nsof_set_error(ctx, NSOF_EINVAL, "bad pair list");
+    if (n_pairs > 32767) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "n_pairs=%d exceeds 32767 per call", n_pairs);
+    if (n_pairs == 0) return NSOF_OK;
+    const Params p{pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+    return het_core(ctx, n_pairs, pairs, p);
+}
+
+extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs, double pyr_scale,
+                                       int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (n_pairs < 0 || (n_pairs > 0 && !pairs)) return nsof_set_error(ctx, NSOF_EINVAL, "bad pair list");
+    if (n_pairs == 0) return NSOF_OK;
+    const Params p{pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+    for (int i = 0; i < n_pairs; i++)
+        if (int rc = validate_desc(ctx, i, pairs[i], p)) return rc;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    nsof_pipe* pp;
+    if (int rc = pipe_get(ctx, &pp)) return rc;
+
+    // chunks of the list: about 1 GiB of flow (64 pairs of 1920x1080) each, so that the stages have work to overlap
+    const char* chunk_env = getenv("NSOF_PIPE_CHUNK_MB");   // tests shrink it to force several chunks
+    const size_t budget = (size_t)std::max(1l, chunk_env ? atol(chunk_env) : 1024l) << 20;
+    std::vector<Chunk> chunks;
+    for (int i = 0; i < n_pairs;) {
+        Chunk c;
+        c.lo = i;
+        while (i < n_pairs && (i == c.lo || (c.out_bytes < budget && i - c.lo < 8192))) {
+            const size_t n0 = (size_t)pairs[i].width * pairs[i].height;
+            for (int f = 0; f < 2; f++) { c.in_off[f].push_back(c.in_bytes); c.in_bytes += align_up(n0, 256); }
+            c.out_off.push_back(c.out_bytes);
+            c.out_bytes += align_up(n0 * 8, 256);
+            i++;
+        }
+        c.hi = i;
+        chunks.push_back(std::move(c));
+    }
+    std::vector<char> pin_in(2 * (size_t)n_pairs), pin_out(n_pairs);
+    for (int i = 0; i < n_pairs; i++) {
+        const nsof_pair_desc& d = pairs[i];
+        pin_in[2 * i] = d.prev_stride == d.width && is_pinned(d.prev);
+        pin_in[2 * i + 1] = d.next_stride == d.width && is_pinned(d.next);
+        pin_out[i] = d.flow_stride == (ptrdiff_t)d.width * 8 && is_pinned(d.flow);
+    }
+
+    auto finish = [&](const Chunk& c, nsof_pipe::Slot& s) -> int {   // flows of a finished chunk -> caller's memory
+        NSOF_HIP(ctx, hipEventSynchronize(s.out_done));
+        std::vector<std::pair<int, int>> rows;   // (item, first row) tasks of 64 rows
+        for (int i = c.lo; i < c.hi; i++)
+            if (!pin_out[i])
+                for (int y = 0; y < pairs[i].height; y += 64) rows.emplace_back(i, y);
+        parallel_rows(rows.size(), [&](size_t t) {
+            const int i = rows[t].first, y0 = rows[t].second;
+            const nsof_pair_desc& d = pairs[i];
+            const char* src = (const char*)s.h_out + c.out_off[i - c.lo];
+            for (int y = y0; y < std::min(y0 + 64, d.height); y++)
+                memcpy((char*)d.flow + (ptrdiff_t)y * d.flow_stride, src + (size_t)y * d.width * 8, (size_t)d.width * 8);
+        });
+        return NSOF_OK;
+    };
+
+    const int nc = (int)chunks.size();
+    std::vector<nsof_pair_desc> dd;
+    for (int ci = 0; ci < nc; ci++) {
+        const Chunk& c = chunks[ci];
+        nsof_pipe::Slot& s = pp->slot[ci & 1];
+        if (ci >= 2) {   // the slot's previous chunk must have left it
+            if (int rc = finish(chunks[ci - 2], s)) return rc;
+        }
+        int rc;
+        if ((rc = grow_dev(ctx, &s.d_in, &s.d_in_bytes, c.in_bytes)) || (rc = grow_dev(ctx, &s.d_out, &s.d_out_bytes, c.out_bytes)) ||
+            (rc = grow_host(ctx, &s.h_in, &s.h_in_bytes, c.in_bytes)) || (rc = grow_host(ctx, &s.h_out, &s.h_out_bytes, c.out_bytes)))
+            return rc;
+        // stage 1: frames -> device (pageable / strided sources are packed into the pinned slot buffer by a few threads)
+        std::vector<std::array<int, 3>> rows;   // (item, frame, first row)
+        for (int i = c.lo; i < c.hi; i++)
+            for (int f = 0; f < 2; f++)
+                if (!pin_in[2 * i + f])
+                    for (int y = 0; y < pairs[i].height; y += 256) rows.push_back({i, f, y});
+        parallel_rows(rows.size(), [&](size_t t) {
+            const int i = rows[t][0], f = rows[t][1], y0 = rows[t][2];
+            const nsof_pair_desc& d = pairs[i];
+            const uint8_t* src = f ? d.next : d.prev;
+            const ptrdiff_t st = f ? d.next_stride : d.prev_stride;
+            uint8_t* dst = (uint8_t*)s.h_in + c.in_off[f][i - c.lo];
+            for (int y = y0; y < std::min(y0 + 256, d.height); y++)
+                memcpy(dst + (size_t)y * d.width, src + (ptrdiff_t)y * st, (size_t)d.width);
+        });
+        bool any_packed = !rows.empty(), all_packed = true;
+        for (int i = c.lo; i < c.hi; i++) all_packed = all_packed && !pin_in[2 * i] && !pin_in[2 * i + 1];
+        if (all_packed) {
+            NSOF_HIP(ctx, hipMemcpyAsync(s.d_in, s.h_in, c.in_bytes, hipMemcpyHostToDevice, pp->s_in));
+        } else {
+            for (int i = c.lo; i < c.hi; i++)
+                for (int f = 0; f < 2; f++) {
+                    const size_t off = c.in_off[f][i - c.lo], n0 = (size_t)pairs[i].width * pairs[i].height;
+                    const void* src = pin_in[2 * i + f] ? (const void*)(f ? pairs[i].next : pairs[i].prev)
+                                                        : (const void*)((char*)s.h_in + off);
+                    NSOF_HIP(ctx, hipMemcpyAsync((char*)s.d_in + off, src, n0, hipMemcpyHostToDevice, pp->s_in));
+                }
+        }
+        (void)any_packed;
+        NSOF_HIP(ctx, hipEventRecord(s.in_done, pp->s_in));
+        // stage 2: compute on the context's stream
+        NSOF_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.in_done, 0));
+        dd.resize(c.hi - c.lo);
+        for (int i = c.lo; i < c.hi; i++) {
+            nsof_pair_desc& d = dd[i - c.lo];
+            d.prev = (const uint8_t*)s.d_in + c.in_off[0][i - c.lo];
+            d.next = (const uint8_t*)s.d_in + c.in_off[1][i - c.lo];
+            d.prev_stride = d.next_stride = pairs[i].width;
+            d.width = pairs[i].width;
+            d.height = pairs[i].height;
+            d.flow = (float*)((char*)s.d_out + c.out_off[i - c.lo]);
+            d.flow_stride = (ptrdiff_t)pairs[i].width * 8;
+        }
+        if ((rc = het_core(ctx, c.hi - c.lo, dd.data(), p))) return rc;
+        NSOF_HIP(ctx, hipEventRecord(s.compute_done, ctx->stream));
+        // stage 3: flow -> host
+        NSOF_HIP(ctx, hipStreamWaitEvent(pp->s_out, s.compute_done, 0));
+        bool none_pinned = true;
+        for (int i = c.lo; i < c.hi; i++) none_pinned = none_pinned && !pin_out[i];
+        if (none_pinned) {
+            NSOF_HIP(ctx, hipMemcpyAsync(s.h_out, s.d_out, c.out_bytes, hipMemcpyDeviceToHost, pp->s_out));
+        } else {
+            for (int i = c.lo; i < c.hi; i++) {
+                const size_t off = c.out_off[i - c.lo], nb = (size_t)pairs[i].width * pairs[i].height * 8;
+                void* dst = pin_out[i] ? (void*)pairs[i].flow : (void*)((char*)s.h_out + off);
+                NSOF_HIP(ctx, hipMemcpyAsync(dst, (char*)s.d_out + off, nb, hipMemcpyDeviceToHost, pp->s_out));
+            }
+        }
+        NSOF_HIP(ctx, hipEventRecord(s.out_done, pp->s_out));
+        // the next chunk's upload may not overwrite this slot's partner before ITS compute has consumed it: the
+        // partner slot is only reused two chunks later, after finish() has waited for its download
+    }
+    for (int ci = std::max(0, nc - 2); ci < nc; ci++)
+        if (int rc = finish(chunks[ci], pp->slot[ci & 1])) return rc;
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NSOF_OK;
+}
+
+extern "C" void* nsof_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void nsof_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}

@@ -17,6 +17,7 @@
 //   * column sums go to LDS (20 KB); thread <-> 2 adjacent pixels forms the row sums and solves.
 //
 // HBM traffic per pixel per iteration: R0 20 + R1 ~20 + flow 8 read, flow 8 written = 56 B (+ halo).
+#include <atomic>
 #include <cstdlib>
 
 #include "nsof_internal.h"
@@ -412,10 +413,12 @@ __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Pla
     }
 }
 
+// Fout / fpitch: the output field and its row pitch in float2 units (W for the dense batch layout; the work-list
+// path writes the last iteration straight into the caller's possibly strided field).
 template <int MH, int COLS, typename FS>
 __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
-                                              const Planes& R1, const FS& F, float2* Fout, int W, int H, int x0,
-                                              int xc, int col, int nsteps, double scale)
+                                              const Planes& R1, const FS& F, float2* Fout, size_t fpitch, int W, int H,
+                                              int x0, int xc, int col, int nsteps, double scale)
 {
     using G = PCGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
@@ -479,7 +482,7 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
         (void)xo; (void)yo;
 #elif defined(NSOF_ABL) && NSOF_ABL == 2   // timing-only build: no row sums / solve
         if (2 * t < SW && yo < H && xo < W) {
-            float2* dst = Fout + (size_t)yo * W + xo;
+            float2* dst = Fout + (size_t)yo * fpitch + xo;
             dst[0] = make_float2((float)sv[2 * buf + hrow][0][2 * t], (float)sv[2 * buf + hrow][1][2 * t]);
             if (xo + 1 < W) dst[1] = make_float2((float)sv[2 * buf + hrow][2][2 * t + 1], (float)sv[2 * buf + hrow][3][2 * t + 1]);
         }
@@ -508,8 +511,8 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
                 o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
                 o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
             }
-            float2* dst = Fout + (size_t)yo * W + xo;
-            if (xo + 1 < W && (W & 1) == 0) {   // xo is even: 16-B aligned
+            float2* dst = Fout + (size_t)yo * fpitch + xo;
+            if (xo + 1 < W && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {   // dense layout, even W: always
                 nsof_store_stream4(reinterpret_cast<float*>(dst), o[0].x, o[0].y, o[1].x, o[1].y);
             } else {
                 dst[0] = o[0];
@@ -528,11 +531,15 @@ struct UpsArgs {
     double scale_x, scale_y;
     float mul;
 };
-template <int MH, int COLS, bool UPS>
+// HET: work-list launch -- blockIdx.z indexes a device table of items of different shapes (nsof_het_item): R0b is
+// the level's expansion buffer, flow_in / flow_out the level's flow buffers (item fields at offF), and with
+// het_final the flow goes to the item's own output field instead.
+template <int MH, int COLS, bool UPS, bool HET = false>
 __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict__ R0b, const float* __restrict__ R1b,
                                                      size_t pair_stride, const float* __restrict__ flow_in,
                                                      float* __restrict__ flow_out, int W, int H, int block_size,
-                                                     UpsArgs ups)
+                                                     UpsArgs ups, const nsof_het_item* __restrict__ items = nullptr,
+                                                     int het_final = 0)
 {
     constexpr int SW = PCGeom<MH, COLS>::SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
@@ -545,8 +552,31 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
     // With the natural (strip, pair) order the 8 strips of a pair land on 8 different L2s and their shared halo
     // columns and gather rows are fetched once per XCD; remapped, an XCD owns whole pairs.
     int strip = blockIdx.x, pair = blockIdx.z;
+    size_t fpitch = 0;
+    if constexpr (HET) {
+        static_assert(!UPS, "the work-list path resamples the flow with its own launch");
+        const nsof_het_item& it = items[blockIdx.z];
+        W = it.wk;
+        H = it.hk;
+        if (blockIdx.x * SW >= W) return;   // block-uniform, before any barrier
+        const size_t nk = (size_t)W * H;
+        R0b += it.offR;
+        R1b = R0b + 5 * nk;
+        pair_stride = 0;
+        pair = 0;
+        flow_in += 2 * it.offF;
+        if (het_final) {
+            flow_out = it.out;
+            fpitch = (size_t)it.out_pitch;
+        } else {
+            flow_out += 2 * it.offF;
+            fpitch = (size_t)W;
+        }
+    } else {
+        fpitch = (size_t)W;
+    }
 #ifndef NSOF_NO_XCD_REMAP
-    {
+    if constexpr (!HET) {
         const unsigned total = gridDim.x * gridDim.z;
         if ((total & 7u) == 0) {
             const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
@@ -580,52 +610,74 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
     const int nsteps = (H + 1) / 2;
     // Each role runs its own loop; all three execute one barrier before the loop and two per step.
     if (role == 0)
-        consumer_loop<MH, COLS>(mring, sv, R0, R1, F, Fout, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
+        consumer_loop<MH, COLS>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps,
+                                1. / (block_size * block_size));
     else if (role == 1)
         producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
     else
         producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
 }
 
+// > 64 KB of dynamic LDS needs the opt-in attribute, once per (kernel instance, device); contexts of several
+// devices and the worker threads of a stream pool may arrive here concurrently.
+template <typename K>
+int lds_opt_in(nsof_ctx* ctx, K kernel, size_t bytes)
+{
+    static std::atomic<unsigned long long> done{0};   // one bit per device ordinal (per template instance)
+    const unsigned long long bit = 1ull << (ctx->device & 63);
+    if (done.load(std::memory_order_acquire) & bit) return NSOF_OK;
+    NSOF_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return NSOF_OK;
+}
+
 template <int MH, int COLS, bool UPS>
-void launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
-                         const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
+int launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                        const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
     using G = PCGeom<MH, COLS>;
-    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in attribute (once per kernel)
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_iterate_pc<MH, COLS, UPS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        attr_set = true;
-    }
+    if (int rc = lds_opt_in(ctx, k_iterate_pc<MH, COLS, UPS>, G::SMEM)) return rc;
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
     hipLaunchKernelGGL((k_iterate_pc<MH, COLS, UPS>), grid, dim3(3 * COLS), G::SMEM, ctx->stream, R0, R1, pair_stride,
                        flow_in, flow_out, W, H, winsize, ups);
+    return NSOF_OK;
+}
+
+template <int MH>
+int launch_iterate_pc_het(nsof_ctx* ctx, int n_items, const nsof_het_item* items, int max_w, const float* R,
+                          const float* flow_in, float* flow_out, bool final, int winsize)
+{
+    using G = PCGeom<MH, 256>;
+    if (int rc = lds_opt_in(ctx, k_iterate_pc<MH, 256, false, true>, G::SMEM)) return rc;
+    dim3 grid((max_w + G::SW - 1) / G::SW, 1, n_items);
+    hipLaunchKernelGGL((k_iterate_pc<MH, 256, false, true>), grid, dim3(3 * 256), G::SMEM, ctx->stream, R, R, (size_t)0,
+                       flow_in, flow_out, 0, 0, winsize, UpsArgs{}, items, final ? 1 : 0);
+    return NSOF_OK;
 }
 
 template <int MH, bool UPS>
-void launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+int launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                        const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
     static const bool narrow = getenv("NSOF_PC_COLS128") != nullptr;   // tuning experiment: 2 blocks of 128 columns per CU
     if (!UPS && narrow)
-        launch_iterate_pc_c<MH, 128, false>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
-    else
-        launch_iterate_pc_c<MH, 256, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        return launch_iterate_pc_c<MH, 128, false>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+    return launch_iterate_pc_c<MH, 256, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
 }
 
 template <bool UPS>
-void launch_iterate_pc_m(nsof_ctx* ctx, int m, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+int launch_iterate_pc_m(nsof_ctx* ctx, int m, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                          const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
     switch (m) {
-        case 1: launch_iterate_pc<1, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
-        case 2: launch_iterate_pc<2, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
-        case 3: launch_iterate_pc<3, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
-        case 4: launch_iterate_pc<4, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
-        case 5: launch_iterate_pc<5, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
-        case 6: launch_iterate_pc<6, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
-        default: launch_iterate_pc<7, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups); break;
+        case 1: return launch_iterate_pc<1, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        case 2: return launch_iterate_pc<2, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        case 3: return launch_iterate_pc<3, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        case 4: return launch_iterate_pc<4, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        case 5: return launch_iterate_pc<5, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        case 6: return launch_iterate_pc<6, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
+        default: return launch_iterate_pc<7, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
     }
 }
 
@@ -663,8 +715,9 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
 {
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     if (use_pc(winsize / 2)) {
-        launch_iterate_pc_m<false>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize,
-                                   UpsArgs{});
+        if (int rc = launch_iterate_pc_m<false>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H,
+                                                winsize, UpsArgs{}))
+            return rc;
         NSOF_HIP(ctx, hipGetLastError());
         return NSOF_OK;
     }
@@ -702,7 +755,31 @@ int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, co
     ups.scale_x = 1. / ((double)W / sw);
     ups.scale_y = 1. / ((double)H / sh);
     ups.mul = mul;
-    launch_iterate_pc_m<true>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, coarse_flow, flow_out, W, H, winsize, ups);
+    if (int rc = launch_iterate_pc_m<true>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, coarse_flow, flow_out, W, H,
+                                           winsize, ups))
+        return rc;
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// Work-list twin of nsof_launch_iterate (role-specialised kernel only: winsize 2..15).
+int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, const float* R,
+                            const float* flow_in, float* flow_out, bool final, int winsize)
+{
+    const int m = winsize / 2;
+    if (m < 1 || m > 7) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "work-list iteration supports winsize 2..15");
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    int rc;
+    switch (m) {
+        case 1: rc = launch_iterate_pc_het<1>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+        case 2: rc = launch_iterate_pc_het<2>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+        case 3: rc = launch_iterate_pc_het<3>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+        case 4: rc = launch_iterate_pc_het<4>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+        case 5: rc = launch_iterate_pc_het<5>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+        case 6: rc = launch_iterate_pc_het<6>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+        default: rc = launch_iterate_pc_het<7>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+    }
+    if (rc) return rc;
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
 }

@@ -81,24 +81,56 @@ __device__ __forceinline__ float col_filter(TapF tk, int ksize, int rr, LoadF hv
     return s;
 }
 
+// Geometry of one image of a pyramid-level launch.  HET == false: the uniform batch (every image has the kernel
+// arguments' shape, image z lives at src + z*img_stride and goes to out + z*wk*hk).  HET == true: image z belongs to
+// work item z/2 of the device table (z & 1: prev / next), see nsof_het_item.
+struct PrepImg {
+    const uint8_t* img;
+    float* dst;
+};
+template <bool HET>
+__device__ __forceinline__ bool prep_geom(PrepImg& g, const uint8_t* src, ptrdiff_t& row_stride, ptrdiff_t img_stride,
+                                          int& W, int& H, int& wk, int& hk, float* out,
+                                          const nsof_het_item* __restrict__ items, int want_flag)
+{
+    if constexpr (HET) {
+        const nsof_het_item& it = items[blockIdx.z >> 1];
+        const int which = blockIdx.z & 1;
+        if (want_flag >= 0 && (it.flags & NSOF_HET_VEC0) != want_flag) return false;
+        W = it.W; H = it.H; wk = it.wk; hk = it.hk;
+        row_stride = (ptrdiff_t)it.src_stride[which];
+        g.img = it.src[which];
+        g.dst = out + it.offI + (size_t)which * wk * hk;
+    } else {
+        g.img = src + (ptrdiff_t)blockIdx.z * img_stride;
+        g.dst = out + (size_t)blockIdx.z * wk * hk;
+    }
+    return true;
+}
+
 // Same-size level (k = 0), generic: one thread per pixel, no resample.
+template <bool HET>
 __global__ __launch_bounds__(256) void k_prep_same(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                     ptrdiff_t img_stride, int W, int H, nsof_blur_taps t,
-                                                    float* __restrict__ out)
+                                                    float* __restrict__ out, const nsof_het_item* __restrict__ items,
+                                                    int want_flag)
 {
     __shared__ float s_tk[NSOF_MAX_BLUR_TAPS];
     if (threadIdx.x < NSOF_MAX_BLUR_TAPS) s_tk[threadIdx.x] = t.k[threadIdx.x];
     __syncthreads();
     auto tk = [&](int j) { return s_tk[j]; };
+    PrepImg g;
+    int wk = W, hk = H;
+    if (!prep_geom<HET>(g, src, row_stride, img_stride, W, H, wk, hk, out, items, want_flag)) return;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    const uint8_t* img = g.img;
     auto hv = [&](int rr) {
         const uint8_t* rowp = img + (ptrdiff_t)reflect101(rr, H) * row_stride;
         return row_filter<0>(tk, t.ksize, x, [&](int c) { return (float)rowp[reflect101(c, W)]; });
     };
-    out[((size_t)blockIdx.z * H + y) * W + x] = col_filter<0>(tk, t.ksize, y, hv);
+    g.dst[(size_t)y * W + x] = col_filter<0>(tk, t.ksize, y, hv);
 }
 
 // Same-size level with the 3-tap kernel (every level 0): a lane owns 4 adjacent pixels of 8 consecutive rows.
@@ -106,18 +138,23 @@ __global__ __launch_bounds__(256) void k_prep_same(const uint8_t* __restrict__ s
 // (the wave's edge lanes fetch theirs from memory); row-filter results are shared between the three
 // output rows that use them; 16-B stores.  Requires 4-byte aligned rows (else k_prep_same).
 constexpr int PREP0_ROWS = 8;
+template <bool HET>
 __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                          ptrdiff_t img_stride, int W, int H, float k0, float k1,
-                                                         float* __restrict__ out)
+                                                         float* __restrict__ out,
+                                                         const nsof_het_item* __restrict__ items)
 {
+    PrepImg g;
+    int wk = W, hk = H;
+    if (!prep_geom<HET>(g, src, row_stride, img_stride, W, H, wk, hk, out, items, NSOF_HET_VEC0)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (blockIdx.x * 64 + lane) * 4;                  // first of this lane's 4 pixels
     const int y0 = (blockIdx.y * 4 + wave) * PREP0_ROWS;
-    if (y0 >= H) return;                                          // wave-uniform
+    if (y0 >= H || blockIdx.x * 256 >= W) return;                 // wave-uniform
     const bool live = x < W;
     const int xl = live ? x : 0;                                  // dead lanes still take part in the shuffles
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
-    float* dst = out + (size_t)blockIdx.z * W * H;
+    const uint8_t* img = g.img;
+    float* dst = g.dst;
 
     auto hrow = [&](int rr, float (&h)[4]) {                      // row filter of source row rr (reflected)
         const uint8_t* rowp = img + (ptrdiff_t)reflect101(rr, H) * row_stride;
@@ -279,19 +316,23 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
 }
 
 // Resampled level, generic fallback: one thread per destination pixel, no data sharing.
+template <bool HET>
 __global__ __launch_bounds__(256) void k_prep_naive(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                      ptrdiff_t img_stride, int W, int H, int wk, int hk,
                                                      double scale_x, double scale_y, nsof_blur_taps t,
-                                                     float* __restrict__ out)
+                                                     float* __restrict__ out, const nsof_het_item* __restrict__ items)
 {
     __shared__ float s_tk[NSOF_MAX_BLUR_TAPS];
     if (threadIdx.x < NSOF_MAX_BLUR_TAPS) s_tk[threadIdx.x] = t.k[threadIdx.x];
     __syncthreads();
     auto tk = [&](int j) { return s_tk[j]; };
+    PrepImg g;
+    prep_geom<HET>(g, src, row_stride, img_stride, W, H, wk, hk, out, items, -1);
+    if constexpr (HET) { scale_x = 1. / ((double)wk / W); scale_y = 1. / ((double)hk / H); }
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= wk || dy >= hk) return;
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    const uint8_t* img = g.img;
     int sx, sy;
     float a1, b1;
     lin_coord_x(dx, scale_x, W, sx, a1);
@@ -308,7 +349,7 @@ __global__ __launch_bounds__(256) void k_prep_naive(const uint8_t* __restrict__ 
     };
     const float t0 = blur(r0, c0) * a0 + blur(r0, c1) * a1;
     const float t1 = blur(r1, c0) * a0 + blur(r1, c1) * a1;
-    out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+    g.dst[(size_t)dy * wk + dx] = t0 * b0 + t1 * b1;
 }
 
 // Resampled level, LDS-tiled: a 32x8 destination tile per 256-thread block.
@@ -318,12 +359,20 @@ __global__ __launch_bounds__(256) void k_prep_naive(const uint8_t* __restrict__ 
 //   phase 4: bilinear blend (horizontal first, then vertical, as resize does)
 // KS = compile-time kernel size (3, 5, 9, 19: pyr_scale 0.5 / 0.6 with up to 3 levels) or 0 = runtime.
 constexpr int PREP_TW = 32, PREP_TH = 8;
-template <int KS>
+template <int KS, bool HET>
 __global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                      ptrdiff_t img_stride, int W, int H, int wk, int hk,
                                                      double scale_x, double scale_y, int rw_cap, int rh_cap,
-                                                     nsof_blur_taps t, float* __restrict__ out)
+                                                     nsof_blur_taps t, float* __restrict__ out,
+                                                     const nsof_het_item* __restrict__ items)
 {
+    PrepImg g;
+    prep_geom<HET>(g, src, row_stride, img_stride, W, H, wk, hk, out, items, -1);
+    if constexpr (HET) {
+        scale_x = 1. / ((double)wk / W);
+        scale_y = 1. / ((double)hk / H);
+        if (blockIdx.x * PREP_TW >= wk || blockIdx.y * PREP_TH >= hk) return;   // block-uniform
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sH = reinterpret_cast<float*>(smem);                 // [rh_cap][2*TW]
     float* sB = sH + (size_t)rh_cap * (2 * PREP_TW);            // [2*TH][2*TW]
@@ -336,7 +385,7 @@ __global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ksize = KS ? KS : t.ksize, r = ksize >> 1;
     const int dx0 = blockIdx.x * PREP_TW, dy0 = blockIdx.y * PREP_TH;
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    const uint8_t* img = g.img;
     auto tk = [&](int j) { return KS ? t.k[j] : s_tk[j]; };   // KS > 0: j is a constant after unrolling
 
     if (tid < PREP_TW) {
@@ -363,7 +412,7 @@ __global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ 
     const int R0 = s_r[0] - r, RH = s_r[2 * PREP_TH - 1] + r - R0 + 1;
     // host sized rw_cap/rh_cap from the same arithmetic (+4 columns of slack for the aligned copy below)
     const bool interior = C0 >= 0 && C0 + RW0 <= W && R0 >= 0 && R0 + RH <= H && (W & 3) == 0 &&
-                          (row_stride & 3) == 0 && (img_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+                          (row_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 3) == 0;
     if (interior) {
         // no border inside the footprint: copy whole aligned dwords (64 lanes x 4 B per wave-instruction)
         const int C0a = C0 & ~3, nd = (C0 + RW0 - C0a + 3) >> 2;
@@ -403,7 +452,7 @@ __global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ 
         const float* B1 = B0 + 2 * PREP_TW;
         const float t0 = B0[0] * a0 + B0[1] * a1;
         const float t1 = B1[0] * a0 + B1[1] * a1;
-        out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+        g.dst[(size_t)dy * wk + dx] = t0 * b0 + t1 * b1;
     }
 }
 
@@ -413,17 +462,20 @@ __global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ 
 // contributes KS+1 consecutive bytes, fetched as unaligned dwords (L1/L2 resident: the u8 frame is 2 MB).
 // More arithmetic than the LDS-tiled variant but no per-tile overhead -- measured 3-6x faster at 1080p.
 // Pixels whose footprint leaves the image take a per-byte path with BORDER_REFLECT_101 indexing.
-template <int KS>
+template <int KS, bool HET>
 __global__ __launch_bounds__(256) void k_prep_direct(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
                                                       ptrdiff_t img_stride, int W, int H, int wk, int hk,
                                                       double scale_x, double scale_y, nsof_blur_taps t,
-                                                      float* __restrict__ out)
+                                                      float* __restrict__ out, const nsof_het_item* __restrict__ items)
 {
     constexpr int R = KS / 2, NB = KS + 1, ND = (NB + 3) / 4;
+    PrepImg g;
+    prep_geom<HET>(g, src, row_stride, img_stride, W, H, wk, hk, out, items, -1);
+    if constexpr (HET) { scale_x = 1. / ((double)wk / W); scale_y = 1. / ((double)hk / H); }
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= wk || dy >= hk) return;
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    const uint8_t* img = g.img;
     int sx, sy;
     float a1, b1;
     lin_coord_x(dx, scale_x, W, sx, a1);
@@ -470,7 +522,7 @@ __global__ __launch_bounds__(256) void k_prep_direct(const uint8_t* __restrict__
     }
     const float t0 = B00 * a0 + B01 * a1;
     const float t1 = B10 * a0 + B11 * a1;
-    out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+    g.dst[(size_t)dy * wk + dx] = t0 * b0 + t1 * b1;
 }
 
 // Resampled level, two passes (kernel sizes 9 and 19: levels 2 and 3 of the reference's parameter sets).
@@ -579,11 +631,25 @@ struct PolyGeom {
     static constexpr int NV = (2 * NP + 4) / 4; // float4 per lane per moment row
 };
 
-template <int N>
+template <int N, bool HET>
 __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, float* __restrict__ R, int W, int H,
-                                                  int seg_rows, nsof_poly_taps tp)
+                                                  int seg_rows, nsof_poly_taps tp,
+                                                  const nsof_het_item* __restrict__ items)
 {
     using G = PolyGeom<N>;
+    size_t img_off, r_off;   // element offsets of this image / its expansion
+    if constexpr (HET) {
+        const nsof_het_item& it = items[blockIdx.z >> 1];
+        const size_t which = blockIdx.z & 1;
+        W = it.wk;
+        H = it.hk;
+        if (blockIdx.x * G::SW >= W || blockIdx.y * seg_rows >= H) return;   // block-uniform, before any barrier
+        img_off = it.offI + which * (size_t)W * H;
+        r_off = it.offR + which * 5 * (size_t)W * H;
+    } else {
+        img_off = (size_t)blockIdx.z * W * H;
+        r_off = (size_t)blockIdx.z * 5 * W * H;
+    }
     __shared__ __attribute__((aligned(16))) float sr[2][3][4][256];
     // The 2N double-precision taps would not fit the scalar register file next to the float taps (SGPR
     // spills cost more than the arithmetic); they live in LDS and are re-read (broadcast) once per step.
@@ -602,8 +668,8 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
     const int ys = blockIdx.y * seg_rows, ye = min(ys + seg_rows, H);
     const unsigned plane = (unsigned)W * (unsigned)H;
     // wave-uniform bases + 32-bit byte offsets: loads/stores stay in "SGPR base + VGPR offset" form
-    const char* Ib = reinterpret_cast<const char*>(img + (size_t)blockIdx.z * plane);
-    char* Rb = reinterpret_cast<char*>(R + (size_t)blockIdx.z * 5 * plane);
+    const char* Ib = reinterpret_cast<const char*>(img + img_off);
+    char* Rb = reinterpret_cast<char*>(R + r_off);
     const int xc = clampi(x0 - G::NP + tid, 0, W - 1);
     auto ld = [&](int row) {
         return *reinterpret_cast<const float*>(Ib + ((unsigned)clampi(row, 0, H - 1) * (unsigned)W + (unsigned)xc) * 4u);
@@ -951,13 +1017,34 @@ __global__ __launch_bounds__(256) void k_flow_upsample(const float* __restrict__
 // consecutive destination coordinates map to source coordinates at most one apart, so the block's 4 pixels
 // sample from a 3x3 source neighbourhood: 9 float2 loads + 2 float4 stores per 4 pixels instead of 16 + 4 (the L1
 // serves 4 lanes per cycle per instruction, whatever its width).  Same arithmetic per pixel as k_flow_upsample.
+template <bool HET>
 __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restrict__ src, int sw, int sh,
                                                            float* __restrict__ dst, int dw, int dh, double scale_x,
-                                                           double scale_y, float mul)
+                                                           double scale_y, float mul,
+                                                           const nsof_het_item* __restrict__ items)
 {
     const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int dx0 = 2 * bx, dy0 = 2 * by;
-    if (dx0 >= dw || dy0 >= dh) return;
+    size_t s_off, d_off;   // float2 offsets of this field in src / dst
+    if constexpr (HET) {
+        const nsof_het_item& it = items[blockIdx.z];
+        sw = it.pw; sh = it.ph; dw = it.wk; dh = it.hk;
+        s_off = it.offFc;
+        d_off = it.offF;
+        if (dx0 >= dw || dy0 >= dh) return;
+        if (sw == 0) {   // the item's coarsest level: its incoming flow is zero
+            float2* D = reinterpret_cast<float2*>(dst) + d_off;
+            for (int i = 0; i < 2 && dy0 + i < dh; i++)
+                for (int j = 0; j < 2 && dx0 + j < dw; j++) D[(size_t)(dy0 + i) * dw + dx0 + j] = make_float2(0.f, 0.f);
+            return;
+        }
+        scale_x = 1. / ((double)dw / sw);
+        scale_y = 1. / ((double)dh / sh);
+    } else {
+        s_off = (size_t)blockIdx.z * sw * sh;
+        d_off = (size_t)blockIdx.z * dw * dh;
+        if (dx0 >= dw || dy0 >= dh) return;
+    }
     int sx[2], sy[2];
     float a1[2], b1[2];
 #pragma unroll
@@ -965,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restric
         lin_coord_x(min(dx0 + i, dw - 1), scale_x, sw, sx[i], a1[i]);
         lin_coord_y(min(dy0 + i, dh - 1), scale_y, sy[i], b1[i]);
     }
-    const float2* S = reinterpret_cast<const float2*>(src) + (size_t)blockIdx.z * sw * sh;
+    const float2* S = reinterpret_cast<const float2*>(src) + s_off;
     // source columns sx[0]+{0,1,2} and rows sy[0]+{0,1,2}, clamped like the per-pixel kernel clamps them
     float2 v[3][3];
 #pragma unroll
@@ -974,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restric
 #pragma unroll
         for (int c = 0; c < 3; c++) v[r][c] = row[min(sx[0] + c, sw - 1)];
     }
-    float2* D = reinterpret_cast<float2*>(dst) + (size_t)blockIdx.z * dw * dh;
+    float2* D = reinterpret_cast<float2*>(dst) + d_off;
 #pragma unroll
     for (int i = 0; i < 2; i++) {          // destination row dy0 + i
         if (dy0 + i >= dh) break;
@@ -999,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restric
             }
         }
         float2* drow = D + (size_t)(dy0 + i) * dw + dx0;
-        if (dx0 + 1 < dw && (dw & 1) == 0)
+        if (dx0 + 1 < dw && (dw & 1) == 0 && (!HET || (d_off & 1) == 0))
             nsof_store_stream4(reinterpret_cast<float*>(drow), o[0].x, o[0].y, o[1].x, o[1].y);
         else {
             drow[0] = o[0];
@@ -1110,7 +1197,22 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
-    hipLaunchKernelGGL(k_polyexp<N>, grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps);
+    hipLaunchKernelGGL((k_polyexp<N, false>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
+}
+
+// Work-list twin: W, H are the largest level extents over the table, n_img = 2 * items.
+template <int N>
+void launch_polyexp_het_n(nsof_ctx* ctx, int n_img, const nsof_het_item* items, const float* img, int W, int H,
+                          const nsof_poly_taps& taps, float* R)
+{
+    using G = PolyGeom<N>;
+    const int strips = (W + G::SW - 1) / G::SW;
+    int segs = 1;
+    while (segs < 64 && (long long)strips * n_img * segs < 2048 && (H / (segs * 2)) >= 64) segs *= 2;
+    int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
+    segs = (H + seg_rows - 1) / seg_rows;
+    dim3 grid(strips, segs, n_img);
+    hipLaunchKernelGGL((k_polyexp<N, true>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, items);
 }
 
 }  // namespace
@@ -1127,12 +1229,12 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
                              (reinterpret_cast<uintptr_t>(src) & 3) == 0 && W >= 8;
         if (taps.ksize == 3 && aligned) {
             dim3 grid((W / 4 + 63) / 64, (H + 4 * PREP0_ROWS - 1) / (4 * PREP0_ROWS), n_img);
-            hipLaunchKernelGGL(k_prep_same3_vec, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H,
-                               taps.k[1], taps.k[2], out);
+            hipLaunchKernelGGL(k_prep_same3_vec<false>, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W,
+                               H, taps.k[1], taps.k[2], out, nullptr);
         } else {
             dim3 grid((W + 63) / 64, (H + 3) / 4, n_img);
-            hipLaunchKernelGGL(k_prep_same, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, taps,
-                               out);
+            hipLaunchKernelGGL(k_prep_same<false>, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H,
+                               taps, out, nullptr, -1);
         }
     } else {
         const double scale_x = 1. / ((double)wk / W), scale_y = 1. / ((double)hk / H);
@@ -1176,8 +1278,8 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
         } else if (direct_ok) {
             dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
 #define NSOF_PREP_DIRECT(KS)                                                                                       \
-    hipLaunchKernelGGL(k_prep_direct<KS>, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk, \
-                       hk, scale_x, scale_y, taps, out)
+    hipLaunchKernelGGL((k_prep_direct<KS, false>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, \
+                       H, wk, hk, scale_x, scale_y, taps, out, nullptr)
             if (taps.ksize == 3) NSOF_PREP_DIRECT(3);
             else NSOF_PREP_DIRECT(5);
 #undef NSOF_PREP_DIRECT
@@ -1195,8 +1297,8 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
         } else if (smem <= 60 * 1024 && scale_x >= 1.0 && scale_y >= 1.0) {
             dim3 grid((wk + PREP_TW - 1) / PREP_TW, (hk + PREP_TH - 1) / PREP_TH, n_img);
 #define NSOF_PREP_TILED(KS)                                                                                        \
-    hipLaunchKernelGGL(k_prep_tiled<KS>, grid, dim3(256), smem, ctx->stream, src, row_stride, img_stride, W, H, wk, \
-                       hk, scale_x, scale_y, rw_cap, rh_cap, taps, out)
+    hipLaunchKernelGGL((k_prep_tiled<KS, false>), grid, dim3(256), smem, ctx->stream, src, row_stride, img_stride, \
+                       W, H, wk, hk, scale_x, scale_y, rw_cap, rh_cap, taps, out, nullptr)
             switch (taps.ksize) {
                 case 9: NSOF_PREP_TILED(9); break;
                 case 19: NSOF_PREP_TILED(19); break;
@@ -1205,8 +1307,8 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
 #undef NSOF_PREP_TILED
         } else {
             dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
-            hipLaunchKernelGGL(k_prep_naive, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk,
-                               hk, scale_x, scale_y, taps, out);
+            hipLaunchKernelGGL(k_prep_naive<false>, grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H,
+                               wk, hk, scale_x, scale_y, taps, out, nullptr);
         }
     }
     NSOF_HIP(ctx, hipGetLastError());
@@ -1270,14 +1372,105 @@ int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int 
     }
     if (dw >= sw && dh >= sh && sw >= 1 && sh >= 1) {   // upsampling: source steps of 0 or 1 between neighbours
         dim3 g2(((dw + 1) / 2 + 63) / 64, ((dh + 1) / 2 + 3) / 4, n_pairs);
-        hipLaunchKernelGGL(k_flow_upsample2x2, g2, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x,
-                           scale_y, mul);
+        hipLaunchKernelGGL(k_flow_upsample2x2<false>, g2, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x,
+                           scale_y, mul, nullptr);
         NSOF_HIP(ctx, hipGetLastError());
         return NSOF_OK;
     }
     dim3 grid((dw + 63) / 64, (dh + 3) / 4, n_pairs);
     hipLaunchKernelGGL(k_flow_upsample, grid, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x, scale_y,
                        mul);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// =========================================================================================
+// work-list (shape-heterogeneous) launchers: one launch per stage and level over a device table
+// =========================================================================================
+int nsof_launch_prep_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
+                         bool level0, const nsof_blur_taps& taps, float* I)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_PREP);
+    int max_wk = 0, max_hk = 0, n_vec = 0;
+    double max_sx = 1, max_sy = 1;
+    for (int i = 0; i < n_items; i++) {
+        const nsof_het_item& it = h_items[i];
+        max_wk = it.wk > max_wk ? it.wk : max_wk;
+        max_hk = it.hk > max_hk ? it.hk : max_hk;
+        n_vec += (it.flags & NSOF_HET_VEC0) ? 1 : 0;
+        const double sx = 1. / ((double)it.wk / it.W), sy = 1. / ((double)it.hk / it.H);
+        max_sx = sx > max_sx ? sx : max_sx;
+        max_sy = sy > max_sy ? sy : max_sy;
+    }
+    const int nz = 2 * n_items;
+    if (level0) {   // same-size level: 3 taps; aligned items take the vector kernel, the others the generic one
+        if (taps.ksize == 3 && n_vec > 0) {
+            dim3 grid((max_wk / 4 + 63) / 64, (max_hk + 4 * PREP0_ROWS - 1) / (4 * PREP0_ROWS), nz);
+            hipLaunchKernelGGL(k_prep_same3_vec<true>, grid, dim3(256), 0, ctx->stream, nullptr, 0, 0, 0, 0, taps.k[1],
+                               taps.k[2], I, d_items);
+        }
+        if (taps.ksize != 3 || n_vec < n_items) {
+            dim3 grid((max_wk + 63) / 64, (max_hk + 3) / 4, nz);
+            hipLaunchKernelGGL(k_prep_same<true>, grid, dim3(256), 0, ctx->stream, nullptr, 0, 0, 0, 0, taps, I, d_items,
+                               taps.ksize == 3 ? 0 : -1);
+        }
+    } else {
+        const int r = taps.ksize / 2;
+        const int rw_cap = ((int)ceil(PREP_TW * max_sx) + 2 * r + 8 + 3) / 4 * 4;
+        const int rh_cap = (int)ceil(PREP_TH * max_sy) + 2 * r + 4;
+        const size_t smem = sizeof(float) * ((size_t)rh_cap * 2 * PREP_TW + 2 * PREP_TH * 2 * PREP_TW) +
+                            (size_t)rh_cap * rw_cap;
+        if (taps.ksize == 3 || taps.ksize == 5) {
+            dim3 grid((max_wk + 63) / 64, (max_hk + 3) / 4, nz);
+            if (taps.ksize == 3)
+                hipLaunchKernelGGL((k_prep_direct<3, true>), grid, dim3(256), 0, ctx->stream, nullptr, 0, 0, 0, 0, 0, 0, 1.,
+                                   1., taps, I, d_items);
+            else
+                hipLaunchKernelGGL((k_prep_direct<5, true>), grid, dim3(256), 0, ctx->stream, nullptr, 0, 0, 0, 0, 0, 0, 1.,
+                                   1., taps, I, d_items);
+        } else if (smem <= 60 * 1024) {
+            dim3 grid((max_wk + PREP_TW - 1) / PREP_TW, (max_hk + PREP_TH - 1) / PREP_TH, nz);
+#define NSOF_PREP_TILED_HET(KS)                                                                                       \
+    hipLaunchKernelGGL((k_prep_tiled<KS, true>), grid, dim3(256), smem, ctx->stream, nullptr, 0, 0, 0, 0, 0, 0, 1., 1., \
+                       rw_cap, rh_cap, taps, I, d_items)
+            switch (taps.ksize) {
+                case 9: NSOF_PREP_TILED_HET(9); break;
+                case 19: NSOF_PREP_TILED_HET(19); break;
+                default: NSOF_PREP_TILED_HET(0); break;
+            }
+#undef NSOF_PREP_TILED_HET
+        } else {
+            dim3 grid((max_wk + 63) / 64, (max_hk + 3) / 4, nz);
+            hipLaunchKernelGGL(k_prep_naive<true>, grid, dim3(256), 0, ctx->stream, nullptr, 0, 0, 0, 0, 0, 0, 1., 1.,
+                               taps, I, d_items);
+        }
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_polyexp_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                            const nsof_poly_taps& taps, const float* I, float* R)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_POLYEXP);
+    const int nz = 2 * n_items;
+    switch (taps.n) {
+#define NSOF_PH(NN) case NN: launch_polyexp_het_n<NN>(ctx, nz, d_items, I, max_w, max_h, taps, R); break
+        NSOF_PH(1); NSOF_PH(2); NSOF_PH(3); NSOF_PH(4); NSOF_PH(5); NSOF_PH(6); NSOF_PH(7); NSOF_PH(8); NSOF_PH(9); NSOF_PH(10);
+#undef NSOF_PH
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "poly_n=%d outside 1..%d", taps.n, NSOF_MAX_POLY_N);
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_flow_upsample_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                                  const float* src, float* dst, float mul)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_UPSAMPLE);
+    dim3 g2(((max_w + 1) / 2 + 63) / 64, ((max_h + 1) / 2 + 3) / 4, n_items);
+    hipLaunchKernelGGL(k_flow_upsample2x2<true>, g2, dim3(256), 0, ctx->stream, src, 0, 0, dst, 0, 0, 1., 1., mul,
+                       d_items);
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
 }

@@ -153,6 +153,11 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     if (ctx->stage) hipFree(ctx->stage);
     if (ctx->tmp) hipFree(ctx->tmp);
     if (ctx->hstage) hipHostFree(ctx->hstage);
+    if (ctx->het_h) hipHostFree(ctx->het_h);
+    if (ctx->het_d) hipFree(ctx->het_d);
+    for (auto ev : ctx->het_ev)
+        if (ev) hipEventDestroy(ev);
+    nsof_pipe_destroy(ctx);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -309,8 +314,8 @@ extern "C" int nsof_farneback_level_size(int width, int height, double pyr_scale
     return NSOF_OK;
 }
 
-static int check_params(nsof_ctx* ctx, int width, int height, double pyr_scale, int levels, int winsize,
-                        int iterations, int poly_n, int flags)
+int nsof_check_farneback_params(nsof_ctx* ctx, int width, int height, double pyr_scale, int levels, int winsize,
+                                int iterations, int poly_n, int flags)
 {
     if (width < 1 || height < 1) return nsof_set_error(ctx, NSOF_ESHAPE, "empty image %dx%d", width, height);
     if ((long long)width * height > (1ll << 27))   // kernels address one image with 32-bit byte offsets
@@ -408,7 +413,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // Core of both device entry points.  sequence == false: n_pairs independent pairs (d_prev[i], d_next[i]);
 // sequence == true: n_pairs + 1 consecutive frames in d_prev (d_next unused), pair i = (frame i, frame i+1) -- every
 // frame's pyramid level and polynomial expansion is then computed once and shared by the two pairs it belongs to.
-static int farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
+int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
                           ptrdiff_t row_stride, ptrdiff_t pair_stride, int width, int height, float* d_flow,
                           double pyr_scale, int levels, int winsize, int iterations, int poly_n, double poly_sigma,
                           int flags)
@@ -418,7 +423,7 @@ static int farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8
     if (!d_prev || !d_next || !d_flow || n_pairs < 1) return nsof_set_error(ctx, NSOF_EINVAL, "null buffer or n_pairs<1");
     if (n_pairs > 32767)   // 2*n_pairs images go on gridDim.z
         return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "n_pairs=%d exceeds 32767 per call", n_pairs);
-    int rc = check_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
+    int rc = nsof_check_farneback_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
     if (rc) return rc;
     if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
@@ -526,7 +531,7 @@ extern "C" int nsof_farneback_u8_batch_dev(nsof_ctx* ctx, int n_pairs, const uin
                                            float* d_flow, double pyr_scale, int levels, int winsize, int iterations,
                                            int poly_n, double poly_sigma, int flags)
 {
-    return farneback_core(ctx, false, n_pairs, d_prev, d_next, row_stride, pair_stride, width, height, d_flow, pyr_scale,
+    return nsof_farneback_core(ctx, false, n_pairs, d_prev, d_next, row_stride, pair_stride, width, height, d_flow, pyr_scale,
                           levels, winsize, iterations, poly_n, poly_sigma, flags);
 }
 
@@ -537,7 +542,7 @@ extern "C" int nsof_farneback_u8_sequence_dev(nsof_ctx* ctx, int n_frames, const
 {
     if (!ctx) return NSOF_EINVAL;
     if (n_frames < 2) return nsof_set_error(ctx, NSOF_EINVAL, "a sequence needs at least 2 frames");
-    return farneback_core(ctx, true, n_frames - 1, d_frames, nullptr, row_stride, frame_stride, width, height, d_flow,
+    return nsof_farneback_core(ctx, true, n_frames - 1, d_frames, nullptr, row_stride, frame_stride, width, height, d_flow,
                           pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags);
 }
 
@@ -548,7 +553,7 @@ extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t p
 {
     if (!ctx) return NSOF_EINVAL;
     if (!prev || !next || !flow) return nsof_set_error(ctx, NSOF_EINVAL, "null image pointer");
-    int rc = check_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
+    int rc = nsof_check_farneback_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
     if (rc) return rc;
     if (flow_stride < (ptrdiff_t)(width * 8)) return nsof_set_error(ctx, NSOF_EINVAL, "flow_stride < width*8");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));

@@ -37,6 +37,15 @@ struct nsof_ctx {
     // row-filtered intermediate of the two-pass pyramid kernels
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
+    // work-list path: per-level item tables (pinned host copy + device copy, two slots used alternately) and the
+    // events that mark the end of each slot's last upload (the pinned copy is rewritten two calls later)
+    void* het_h = nullptr;
+    void* het_d = nullptr;
+    size_t het_bytes = 0;
+    hipEvent_t het_ev[2] = {nullptr, nullptr};
+    int het_flip = 0;
+    // pipelined host entry (nsof_farneback_u8_batch): copy streams, per-slot staging and events
+    struct nsof_pipe* pipe = nullptr;
 };
 
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
@@ -61,6 +70,16 @@ struct nsof_prof_scope {
     ~nsof_prof_scope();
 };
 
+// ---- Farneback driver pieces shared between nsof_api.hip and farneback_batch.hip -------------------------------
+int nsof_check_farneback_params(nsof_ctx* ctx, int width, int height, double pyr_scale, int levels, int winsize,
+                                int iterations, int poly_n, int flags);
+// Uniform-shape device batch (sequence == true: n_pairs + 1 consecutive frames in d_prev).
+int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t* d_prev, const uint8_t* d_next,
+                        ptrdiff_t row_stride, ptrdiff_t pair_stride, int width, int height, float* d_flow,
+                        double pyr_scale, int levels, int winsize, int iterations, int poly_n, double poly_sigma,
+                        int flags);
+void nsof_pipe_destroy(nsof_ctx* ctx);
+
 // ---- Farneback launchers (farneback_kernels.hip) ------------------------------------------
 struct nsof_blur_taps {
     int ksize;
@@ -76,7 +95,38 @@ struct nsof_poly_taps {
 int nsof_host_blur_taps(int ksize, double sigma, nsof_blur_taps* out);
 int nsof_host_poly_taps(int n, double sigma, nsof_poly_taps* out);
 
+// ---- shape-heterogeneous work lists (nsof_farneback_u8_batch*) ------------------------------------------------
+// One work item (a frame pair of its own shape) at ONE pyramid level.  The host builds one table per level (items
+// that have no such level are left out) and every stage is launched once per level over the whole table:
+// gridDim.z indexes the table (x2 for the per-image stages), gridDim.x/y are sized for the largest item and the
+// workgroups outside an item's extent leave at once.  Offsets are element offsets into the level's workspace
+// buffers: I (level images, f32; prev at offI, next at offI + wk*hk), R (expansions, f32; R0 at offR, R1 at
+// offR + 5*wk*hk), flow (float2; this level at offF, the coarser level's field at offFc).
+struct nsof_het_item {
+    const uint8_t* src[2];       // full-resolution u8 frames (prev, next), device memory
+    long long src_stride[2];     // their row strides in bytes
+    float* out;                  // the caller's flow field of this item (written by the last iteration of level 0)
+    long long out_pitch;         // its row pitch in float2 units
+    unsigned long long offI, offR, offF, offFc;
+    int W, H;                    // full resolution
+    int wk, hk;                  // this level
+    int pw, ph;                  // coarser level (0: the item starts here, its incoming flow is zero)
+    int flags;                   // NSOF_HET_VEC0: both frames 4-byte aligned with W % 4 == 0 (vector level-0 kernel)
+    int pad_;
+};
+enum { NSOF_HET_VEC0 = 1 };
+
 // All launchers are asynchronous on ctx->stream and return an nsof_status.
+// The *_het twins take a device table of n_items entries; max_* are the largest extents over the table.
+int nsof_launch_prep_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
+                         bool level0, const nsof_blur_taps& taps, float* I);
+int nsof_launch_polyexp_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                            const nsof_poly_taps& taps, const float* I, float* R);
+int nsof_launch_flow_upsample_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                                  const float* src, float* dst, float mul);
+// final: the flow goes to the items' own output fields (out / out_pitch) instead of flow_out.
+int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, const float* R,
+                            const float* flow_in, float* flow_out, bool final, int winsize);
 int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
                      int H, int wk, int hk, const nsof_blur_taps& taps, float* out);
 int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps,

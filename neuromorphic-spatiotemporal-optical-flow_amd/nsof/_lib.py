@@ -15,6 +15,12 @@ K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_SEGMENT, 
 
 _vp, _i, _d, _f, _sz, _pd, _i64 = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t, C.c_ssize_t, C.c_int64
 
+class PairDesc(C.Structure):
+    """``nsof_pair_desc`` of include/nsof.h: one frame pair of a shape-heterogeneous batch."""
+    _fields_ = [("prev", _vp), ("prev_stride", _pd), ("next", _vp), ("next_stride", _pd), ("width", _i), ("height", _i),
+                ("flow", _vp), ("flow_stride", _pd)]
+
+
 # name -> (restype, argtypes); every symbol include/nsof.h declares
 SIGNATURES = {
     "nsof_create": (_i, [_i, C.POINTER(_vp)]),
@@ -26,6 +32,10 @@ SIGNATURES = {
     "nsof_farneback_u8": (_i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp, _pd, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_batch_dev": (_i, [_vp, _i, _vp, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_sequence_dev": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
+    "nsof_farneback_u8_batch": (_i, [_vp, _i, C.POINTER(PairDesc), _d, _i, _i, _i, _i, _d, _i]),
+    "nsof_farneback_u8_batch_desc_dev": (_i, [_vp, _i, C.POINTER(PairDesc), _d, _i, _i, _i, _i, _d, _i]),
+    "nsof_host_alloc": (_vp, [_sz]),
+    "nsof_host_free": (None, [_vp]),
     "nsof_farneback_effective_levels": (_i, [_i, _i, _d, _i]),
     "nsof_farneback_level_size": (_i, [_i, _i, _d, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_d)]),
     "nsof_stage_pyr_level": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _d, _i, _vp]),

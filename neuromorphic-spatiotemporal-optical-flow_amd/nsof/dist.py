@@ -111,24 +111,38 @@ def band_slice_bounds(t_all, t_band, slice_us):
     return np.searchsorted(np.asarray(t_band), bounds, side="left").astype(np.int64)
 
 
-def simulate_banded(x, y, p, t, sensor_hw, slice_us, simulate_band, dst=0):
+def collective_device(device=None):
+    """Device the collectives of the current process group need their tensors on: RCCL ("nccl") only moves GPU
+    memory, gloo only host memory.  ``device`` overrides (e.g. ``cuda:LOCAL_RANK`` chosen by the caller)."""
+    if device is not None:
+        return torch.device(device)
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())))
+    return torch.device("cpu")
+
+
+def simulate_banded(x, y, p, t, sensor_hw, slice_us, simulate_band, dst=0, device=None):
     """Scheme-1 accumulator over row bands, one band per rank: every rank filters the (replicated, tiny) event stream
     to its band, runs ``simulate_band(xb, yb, pb, tb, idx_b, (rows, W)) -> w [rows][W] float32`` (on a GPU:
     ``Accumulator(rows, W, 1, ...).step(...)`` then ``.w()``), and the bands are gathered on ``dst`` (the only
-    collective).  Scheme 2 couples pixels through the slice's first/last timestamps and is run per independent
-    stream instead."""
+    collective, issued on ``device`` -- default: the GPU of this rank under RCCL, host memory under gloo).  Scheme 2
+    couples pixels through the slice's first/last timestamps and is run per independent stream instead."""
     import numpy as np
     rank, world = dist.get_rank(), dist.get_world_size()
     H, W = sensor_hw  # noqa: N806
     y0, y1 = band_bounds(H, world)[rank]
     xb, yb, pb, tb, _ = events_in_band(x, y, p, t, y0, y1)
     idx = band_slice_bounds(t, tb, slice_us)
-    w_local = torch.as_tensor(np.ascontiguousarray(simulate_band(xb, yb, pb, tb, idx, (y1 - y0, W)), np.float32))
+    dev = collective_device(device)
+    w_band = simulate_band(xb, yb, pb, tb, idx, (y1 - y0, W))
+    if not torch.is_tensor(w_band):
+        w_band = torch.as_tensor(np.ascontiguousarray(w_band, np.float32))
     cap = max(hi - lo for lo, hi in band_bounds(H, world))
-    buf = torch.zeros((cap, W), dtype=torch.float32, device=w_local.device)
-    buf[:y1 - y0] = w_local
+    buf = torch.zeros((cap, W), dtype=torch.float32, device=dev)
+    if y1 > y0:
+        buf[:y1 - y0] = w_band.to(dev).reshape(y1 - y0, W)
     parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, parts, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(band_bounds(H, world))], 0)
+    return torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(band_bounds(H, world))], 0).cpu()

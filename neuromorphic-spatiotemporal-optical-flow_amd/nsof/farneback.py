@@ -103,6 +103,116 @@ def farneback_sequence(d_frames, d_flow, n_frames, height, width, params, *, row
     ctx.check(rc, "farneback_sequence")
 
 
+class _PinnedOwner:
+    """Keeps a page-locked allocation alive for as long as numpy views of it exist."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        self.ptr = self._lib.nsof_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise MemoryError(f"nsof_host_alloc({nbytes}) failed")
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._lib.nsof_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """``np.empty`` in page-locked host memory: frames / flow fields in such arrays are copied to and from the GPU
+    directly by ``farneback_pairs`` (no staging copy on the host)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    owner = _PinnedOwner(n)
+    buf = (C.c_char * max(n, 1)).from_address(owner.ptr)
+    arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    buf._nsof_owner = owner          # numpy keeps `buf` alive as the array's base; `buf` keeps the allocation
+    return arr
+
+
+def _desc_array(pairs, flows, host):
+    """ctypes array of nsof_pair_desc for (prev, next) pairs and their flow fields (numpy arrays or, with
+    host=False, objects exposing data_ptr()/shape/stride() like torch CUDA tensors)."""
+    descs = (_lib.PairDesc * len(pairs))()
+    keep = []
+    for i, ((prev, nxt), flow) in enumerate(zip(pairs, flows)):
+        d = descs[i]
+        if host:
+            prev, nxt = _as_gray_u8(prev, "prev"), _as_gray_u8(nxt, "next")
+            if prev.shape != nxt.shape:
+                raise NsofValueError(f"pair {i}: prev {prev.shape} and next {nxt.shape} sizes differ", _lib.NSOF_ESHAPE)
+            keep += [prev, nxt]
+            h, w = prev.shape
+            d.prev, d.prev_stride, d.next, d.next_stride = prev.ctypes.data, prev.strides[0], nxt.ctypes.data, nxt.strides[0]
+            d.flow, d.flow_stride = flow.ctypes.data, flow.strides[0]
+        else:
+            h, w = int(prev.shape[0]), int(prev.shape[1])
+            if tuple(nxt.shape[:2]) != (h, w):
+                raise NsofValueError(f"pair {i}: prev and next sizes differ", _lib.NSOF_ESHAPE)
+            if prev.stride(1) != 1 or nxt.stride(1) != 1 or flow.stride(2) != 1 or flow.stride(1) != 2:
+                raise NsofValueError(f"pair {i}: pixel strides must be 1 (row strides are free)")
+            d.prev, d.prev_stride, d.next, d.next_stride = prev.data_ptr(), prev.stride(0), nxt.data_ptr(), nxt.stride(0)
+            d.flow, d.flow_stride = flow.data_ptr(), flow.stride(0) * 4
+        if h == 0 or w == 0:
+            raise NsofValueError(f"pair {i}: empty input image", _lib.NSOF_ESHAPE)
+        d.width, d.height = w, h
+    return descs, keep
+
+
+def farneback_pairs(pairs, params, flows=None, *, pinned=False, ctx=None):
+    """Flow of MANY independent (prev, next) pairs of ANY shapes with one parameter set -- the gated path's ROI
+    calls (optical_flow_seg.py:129-164, :186-203) and full-frame calls (:492-496) of a whole sequence in one go
+    (``nsof_farneback_u8_batch``): the pairs share every kernel launch and upload / compute / download overlap.
+
+    ``pairs``: [(prev, next), ...] uint8 2-D numpy arrays (strided ROI views allowed).  ``flows``: optional list of
+    float32 (h, w, 2) arrays to write into (views ``canvas[y0:y1, x0:x1]`` of a frame-sized canvas are written in
+    place -- the paste of :162/:204); by default fresh arrays are returned, page-locked when ``pinned`` (then the
+    result is copied straight from the GPU into the array).  Each result equals ``calcOpticalFlowFarneback`` of
+    that pair bit for bit."""
+    ctx = ctx or default_context()
+    kw = params.as_kwargs() if hasattr(params, "as_kwargs") else dict(params)
+    pairs = list(pairs)
+    if flows is None:
+        alloc = pinned_empty if pinned else np.empty
+        flows = [alloc((p.shape[0], p.shape[1], 2), np.float32) for p, _ in pairs]
+    else:
+        flows = list(flows)
+        for i, ((p, _), f) in enumerate(zip(pairs, flows)):
+            if not (isinstance(f, np.ndarray) and f.dtype == np.float32 and f.shape == (p.shape[0], p.shape[1], 2)
+                    and f.strides[2] == 4 and f.strides[1] == 8 and f.flags.writeable):
+                raise NsofValueError(f"flows[{i}] must be a writeable float32 ({p.shape[0]}, {p.shape[1]}, 2) array "
+                                     "with contiguous pixels")
+    if len(flows) != len(pairs):
+        raise NsofValueError("flows and pairs differ in length")
+    if not pairs:
+        return []
+    descs, keep = _desc_array(pairs, flows, host=True)
+    rc = ctx._lib.nsof_farneback_u8_batch(ctx.ptr, len(pairs), descs, float(kw["pyr_scale"]), int(kw["levels"]),
+                                          int(kw["winsize"]), int(kw["iterations"]), int(kw["poly_n"]),
+                                          float(kw["poly_sigma"]), int(kw["flags"]))
+    ctx.check(rc, "farneback_pairs")
+    del keep
+    return flows
+
+
+def farneback_pairs_dev(pairs, flows, params, *, ctx=None):
+    """Device-resident twin (``nsof_farneback_u8_batch_desc_dev``): ``pairs`` = [(prev, next), ...] of uint8 CUDA
+    tensors (any row stride: crops ``frame[y0:y1, x0:x1]`` of frames in HBM), ``flows`` = float32 (h, w, 2) CUDA
+    tensors or crops of a frame-sized canvas, written in place.  Asynchronous on the context's stream."""
+    ctx = ctx or default_context()
+    kw = params.as_kwargs() if hasattr(params, "as_kwargs") else dict(params)
+    pairs, flows = list(pairs), list(flows)
+    if len(flows) != len(pairs):
+        raise NsofValueError("flows and pairs differ in length")
+    if not pairs:
+        return
+    descs, _ = _desc_array(pairs, flows, host=False)
+    rc = ctx._lib.nsof_farneback_u8_batch_desc_dev(ctx.ptr, len(pairs), descs, float(kw["pyr_scale"]), int(kw["levels"]),
+                                                   int(kw["winsize"]), int(kw["iterations"]), int(kw["poly_n"]),
+                                                   float(kw["poly_sigma"]), int(kw["flags"]))
+    ctx.check(rc, "farneback_pairs_dev")
+
+
 def effective_levels(width, height, pyr_scale, levels):
     return _lib.load().nsof_farneback_effective_levels(width, height, pyr_scale, levels)
 

@@ -1,0 +1,281 @@
+"""Shape-heterogeneous batches (nsof_farneback_u8_batch*) and the multi-dataset harness (BASELINE config 4).
+
+CPU part: the call list the harness derives from the reference's own gating data (tests/golden/gating_stacks.npz =
+data/*/constructed_3D_matrix.mat in full) and its round-robin sharding (gloo, world size 2).
+GPU part: every call of a work list equals the per-call path bit for bit and the CPU oracle to 1e-5 px, for ROI
+crops (strided views, unaligned origins) and full frames of the five datasets' real sizes and parameter sets.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, PKG, ROOT
+
+A = (0.5, 3, 15, 3, 5, 1.2, 0)
+
+
+@pytest.fixture(scope="module")
+def stacks():
+    with np.load(os.path.join(GOLDEN, "gating_stacks.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _small_frames(wl, stacks, n_pairs):
+    return {name: wl.synthetic_sequence(7 + k, n_pairs + 1, *wl.DATASET_FRAMES[name][:2])
+            for k, name in enumerate(stacks)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU: call list and sharding
+# ---------------------------------------------------------------------------------------------------------------
+def test_call_list_matches_reference_rectangles(nsof_lib, stacks):
+    """ROI rectangles of the first pairs equal those SURVEY.md section 8f derived from the same .mat files, the
+    call list has one full-frame call per pair, and ROI flows are views of the pair's canvas."""
+    from nsof import workload as wl
+    calls, canvases = wl.mixed_workload(stacks, pairs_per_dataset=3, frames=_small_frames(wl, stacks, 3))
+    by = {}
+    for c in calls:
+        by.setdefault((c.dataset, c.kind), []).append(c)
+    assert [c.rect for c in by[("grasp", "roi")]][:3] == [(460, 0, 1060, 1920), (300, 0, 1060, 1140),
+                                                          (540, 940, 1060, 1140)]
+    assert [c.rect for c in by[("tabletennis", "roi")]][:2] == [(0, 0, 160, 160), (70, 10, 160, 160)]
+    # uavnew2 is FLAG 1 (one call per component); its union boxes are the rectangles SURVEY lists
+    from nsof import gating
+    cfg2 = gating.dataset_config("uavnew2", FLAG=2)
+    merged = [wl.roi_rects(gating.gating_maps(stacks["uavnew2"], i, cfg2)[1], (600, 600), cfg2) for i in range(2)]
+    assert merged == [[(0, 60, 600, 600)], [(180, 100, 420, 340)]]
+    per_comp = [c.rect for c in by[("uavnew2", "roi")] if c.pair == 2]
+    assert per_comp == [(220, 100, 380, 260), (260, 140, 420, 300), (220, 180, 380, 340)]
+    for name in stacks:
+        assert len(by[(name, "full")]) == 3 and len(canvases[name]) == 3
+        for c in by.get((name, "roi"), []):
+            x0, y0, x1, y1 = c.rect
+            assert c.prev.shape == (y1 - y0, x1 - x0) == c.flow.shape[:2]
+            assert np.shares_memory(c.flow, canvases[name][c.pair])
+    # parameter sets follow data/*/Parameters.txt
+    from nsof.farneback import PARAMS_A, PARAMS_B, PARAMS_C
+    want = {"grasp": PARAMS_A, "uavnew2": PARAMS_A, "autodriving": PARAMS_B, "uav": PARAMS_B, "tabletennis": PARAMS_C}
+    assert all(c.params == want[c.dataset] for c in calls)
+
+
+def test_full_workload_counts(nsof_lib, stacks):
+    """All consecutive pairs of the five sequences: 99+98+98+46+19 full-frame
+    calls; frames are not needed to count calls, so 2-frame stand-ins are tiled."""
+    from nsof import gating
+    from nsof import workload as wl
+    n_full = n_roi = 0
+    for name, (h, w, n_frames) in wl.DATASET_FRAMES.items():
+        cfg = gating.dataset_config(name)
+        n = min(n_frames - 2, stacks[name].shape[2] - cfg.OFFSET)
+        for i in range(n):
+            n_roi += len(wl.roi_rects(gating.gating_maps(stacks[name], i, cfg)[1], (h, w), cfg))
+        n_full += n
+    assert n_full == 99 + 98 + 98 + 46 + 19
+    assert n_roi > 200
+
+
+def _fake_pairs(pairs, params, flows):
+    for (p, q), f in zip(pairs, flows):
+        f[..., 0] = p.astype(np.float32) - q
+        f[..., 1] = float(params.winsize)
+
+
+def _shard_worker(rank, world, port, ret):
+    for p_ in (ROOT, PKG):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from nsof import dist as nd
+    from nsof import workload as wl
+    nd.init_from_env("gloo")
+    with np.load(os.path.join(GOLDEN, "gating_stacks.npz")) as z:
+        st = {k: z[k] for k in ("uav", "tabletennis")}
+    frames = {name: wl.synthetic_sequence(3 + k, 5, *wl.DATASET_FRAMES[name][:2]) for k, name in enumerate(st)}
+    calls, _ = wl.mixed_workload(st, pairs_per_dataset=4, frames=frames)
+    mine = wl.shard_calls(calls, rank, world)
+    wl.run_calls(mine, pairs_fn=_fake_pairs)
+    sums = [(i, float(c.flow.astype(np.float64).sum())) for i, c in zip(range(rank, len(calls), world), mine)]
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(sums, gathered, dst=0)
+    t = nd.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        wl.run_calls(calls, pairs_fn=_fake_pairs)           # unsharded reference
+        want = {i: float(c.flow.astype(np.float64).sum()) for i, c in enumerate(calls)}
+        got = {i: s for part in gathered for i, s in part}
+        ret.put(bool(got == want and t == float(world) and len(got) == len(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_robin_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29700 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: work list == per call == oracle
+# ---------------------------------------------------------------------------------------------------------------
+def _crops(seed, shapes, frame_hw=(700, 900)):
+    """Strided ROI views of one big frame pair at unaligned origins."""
+    from nsof import synth
+    prev, nxt = synth.make_pair(seed, *frame_hw)
+    rng = np.random.default_rng(seed)
+    out = []
+    for (h, w) in shapes:
+        y0 = int(rng.integers(0, frame_hw[0] - h + 1))
+        x0 = int(rng.integers(0, frame_hw[1] - w + 1))
+        out.append((prev[y0:y0 + h, x0:x0 + w], nxt[y0:y0 + h, x0:x0 + w]))
+    return out
+
+
+SHAPES = [(200, 520), (131, 97), (64, 64), (33, 70), (300, 301), (48, 200), (520, 200), (40, 40), (2, 2), (1, 9),
+          (161, 161), (256, 512)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [A, (0.6, 3, 3, 3, 10, 1.05, 0), (0.6, 3, 4, 2, 1, 1.05, 0), (0.75, 5, 8, 1, 3, 0.9, 0)])
+def test_work_list_equals_per_call(nsof_lib, ctx, params):
+    nsof = nsof_lib
+    p = nsof.FarnebackParams(*params)
+    pairs = _crops(11, SHAPES)
+    got = nsof.farneback_pairs(pairs, p, ctx=ctx)
+    for (a, b), g in zip(pairs, got):
+        want = nsof.calcOpticalFlowFarneback(a, b, None, **p.as_kwargs(), ctx=ctx)
+        assert g.shape == want.shape and g.dtype == np.float32
+        assert np.array_equal(g, want), (a.shape, float(np.abs(g - want).max()))
+
+
+@pytest.mark.gpu
+def test_work_list_vs_oracle_and_canvas_paste(nsof_lib, ctx, oracle):
+    """ROI flows written in place into frame-sized canvases (the paste of optical_flow_seg.py:162/204), pinned and
+    pageable targets, several pipeline chunks; compared with the CPU oracle."""
+    nsof = nsof_lib
+    p = nsof.FarnebackParams(*A)
+    pairs = _crops(5, SHAPES[:8])
+    canvases = [np.zeros((600, 640, 2), np.float32) for _ in pairs]
+    flows = [c[7:7 + a.shape[0], 3:3 + a.shape[1]] for c, (a, _) in zip(canvases, pairs)]
+    os.environ["NSOF_PIPE_CHUNK_MB"] = "1"            # ~1 MiB of flow per chunk: the list takes several chunks
+    try:
+        nsof.farneback_pairs(pairs, p, flows, ctx=ctx)
+        pinned = nsof.farneback_pairs(pairs, p, pinned=True, ctx=ctx)
+    finally:
+        del os.environ["NSOF_PIPE_CHUNK_MB"]
+    for (a, b), f, c, pf in zip(pairs, flows, canvases, pinned):
+        ref = oracle.farneback(np.ascontiguousarray(a), np.ascontiguousarray(b), *A)
+        assert float(np.abs(f - ref).max()) <= 1e-5
+        assert np.array_equal(pf, f)
+        outside = c.copy()
+        outside[7:7 + a.shape[0], 3:3 + a.shape[1]] = 0
+        assert not outside.any()                       # nothing outside the ROI was touched
+
+
+@pytest.mark.gpu
+def test_work_list_device_crops(nsof_lib, ctx, torch_dev):
+    """Device-resident twin: crops of frames already in HBM, flows into crops of a device canvas."""
+    import torch
+    nsof = nsof_lib
+    from nsof import synth
+    p = nsof.FarnebackParams(*A)
+    prev, nxt = synth.make_pair(21, 480, 640)
+    dp, dn = torch.from_numpy(prev).to(torch_dev), torch.from_numpy(nxt).to(torch_dev)
+    canvas = torch.zeros((480, 640, 2), dtype=torch.float32, device=torch_dev)
+    full = torch.empty((480, 640, 2), dtype=torch.float32, device=torch_dev)
+    rects = [(17, 33, 217, 293), (300, 100, 631, 431), (0, 0, 640, 480)]
+    torch.cuda.synchronize()
+    pairs = [(dp[y0:y1, x0:x1], dn[y0:y1, x0:x1]) for x0, y0, x1, y1 in rects]
+    flows = [canvas[y0:y1, x0:x1] for x0, y0, x1, y1 in rects[:2]] + [full]
+    nsof.farneback_pairs_dev(pairs, flows, p, ctx=ctx)
+    ctx.synchronize()
+    for (x0, y0, x1, y1), f in zip(rects, flows):
+        want = nsof.calcOpticalFlowFarneback(prev[y0:y1, x0:x1], nxt[y0:y1, x0:x1], None, **p.as_kwargs(), ctx=ctx)
+        assert np.array_equal(f.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_config4_mixed_datasets_vs_oracle(nsof_lib, ctx, oracle, stacks):
+    """BASELINE config 4 on one GPU: grasp + autodriving + uav + uavnew2 + tabletennis, each with its
+    Parameters.txt, gated (ROI) and full-frame calls, frames of the real sizes; every flow vs the CPU oracle."""
+    from nsof import workload as wl
+    calls, canvases = wl.mixed_workload(stacks, pairs_per_dataset=2)
+    assert {c.dataset for c in calls} == set(wl.DATASET_FRAMES) and {c.kind for c in calls} == {"roi", "full"}
+    wl.run_calls(calls, ctx=ctx)
+    worst = 0.0
+    for c in calls:
+        ref = oracle.farneback(np.ascontiguousarray(c.prev), np.ascontiguousarray(c.next),
+                               *[getattr(c.params, k) for k in ("pyr_scale", "levels", "winsize", "iterations",
+                                                                "poly_n", "poly_sigma", "flags")])
+        worst = max(worst, float(np.abs(c.flow - ref).max()))
+    assert worst <= 1e-5, worst
+    # the one-call-at-a-time pattern of the reference gives the same bits
+    again, _ = wl.mixed_workload(stacks, pairs_per_dataset=2)
+    wl.run_calls_one_by_one(again, ctx=ctx)
+    assert all(np.array_equal(a.flow, b.flow) for a, b in zip(calls, again))
+
+
+@pytest.mark.gpu
+def test_real_frames_through_harness(nsof_lib, ctx, oracle, stacks):
+    """The reference's own first frames (tests/golden/frames/*, demo/grasp_*.jpg) through the gated + full-frame
+    calls with each dataset's parameters, vs the oracle -- the 801x801 autodriving frames included."""
+    pil = pytest.importorskip("PIL.Image")
+    from nsof import gating
+    from nsof import workload as wl
+
+    def load(paths):
+        out = []
+        for pth in paths:
+            bgr = np.ascontiguousarray(np.asarray(pil.open(pth).convert("RGB"))[..., ::-1])
+            out.append(gating.frame_to_gray(bgr, "RGB2GRAY"))
+        return out
+
+    frames = {"grasp": load([os.path.join(GOLDEN, "demo", f"grasp_{k}.jpg") for k in (1, 2)])}
+    for name in ("autodriving", "uav", "uavnew2", "tabletennis"):
+        d = os.path.join(GOLDEN, "frames", name)
+        frames[name] = load([os.path.join(d, f) for f in sorted(os.listdir(d), key=lambda s: int(s.split(".")[0]))])
+    for name, fr in frames.items():
+        assert fr[0].shape == wl.DATASET_FRAMES[name][:2]
+    calls, _ = wl.mixed_workload(stacks, frames=frames, pairs_per_dataset=2)
+    wl.run_calls(calls, ctx=ctx)
+    for c in calls:
+        ref = oracle.farneback(np.ascontiguousarray(c.prev), np.ascontiguousarray(c.next),
+                               *[getattr(c.params, k) for k in ("pyr_scale", "levels", "winsize", "iterations",
+                                                                "poly_n", "poly_sigma", "flags")])
+        assert float(np.abs(c.flow - ref).max()) <= 1e-5, (c.dataset, c.kind, c.rect)
+
+
+@pytest.mark.gpu
+def test_roi_batch_is_cheaper_than_one_by_one(nsof_lib, ctx, torch_dev):
+    """64 ROI pairs of 520x200 (the typical grasp crop) in one work list: well under 0.1 ms per pair on the device
+    (one at a time: ~0.95 ms each)."""
+    import time
+
+    import torch
+    nsof = nsof_lib
+    p = nsof.FarnebackParams(*A)
+    g = torch.Generator(device=torch_dev).manual_seed(0)
+    frames = torch.randint(0, 256, (2, 1080, 1920), dtype=torch.uint8, device=torch_dev, generator=g)
+    canvas = torch.zeros((64, 200, 520, 2), dtype=torch.float32, device=torch_dev)
+    pairs = [(frames[0, 8 * i:8 * i + 200, 13 * i:13 * i + 520], frames[1, 8 * i:8 * i + 200, 13 * i:13 * i + 520])
+             for i in range(64)]
+    flows = [canvas[i] for i in range(64)]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        nsof.farneback_pairs_dev(pairs, flows, p, ctx=ctx)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        nsof.farneback_pairs_dev(pairs, flows, p, ctx=ctx)
+    ctx.synchronize()
+    per_pair_ms = (time.perf_counter() - t0) / 5 / 64 * 1e3
+    assert per_pair_ms < 0.1, per_pair_ms
