@@ -176,6 +176,7 @@ def main():
             prof[k] = ctx.prof_collect(k)
         ctx.prof_enable()
 
+    exit_code = 0
     if rank == 0:
         total_pairs = n * world * args.steps
         alg = algorithmic_bytes_per_pair(nsof, w, h, p)
@@ -215,36 +216,85 @@ def main():
                     tr = json.load(f).get("kernels", {})
                 for key in ("roofline", "roofline_polyexp"):
                     ent = tr.get(out[key]["kernel"]) if out.get(key) else None
-                    if ent is not None:
+                    if ent is not None:   # NOT counters of this run: a stored PMC ratio applied to this run's bytes
                         out[key]["traffic"] = int(out[key]["algorithmic_bytes_per_launch"] *
                                                   ent["traffic_over_algorithmic"])
+                        out[key]["traffic_source"] = ("estimated: algorithmic bytes x PMC ratio "
+                                                      f"{ent['traffic_over_algorithmic']} from profiles/hbm_traffic.json "
+                                                      "(rocprofv3 --pmc pass of scripts/stage_bench.py, see its _doc)")
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         print(json.dumps(out))
+        if out.get("parity_ok") is False:
+            print(f"bench: GPU flow differs from the CPU baseline by more than {out['epe_tolerance']}", file=sys.stderr)
+            exit_code = 3
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 def cpu_leg(nsof, p, prevs, nexts, flow, k):
-    """CPU oracle on the first k pairs of this run's batch: throughput (1 thread) and max-abs EPE GPU vs oracle."""
+    """CPU baseline on the first k pairs of this run's batch, timed on this box's host cores:
+    cv2 itself when it is importable (``kind: reference``: 1 thread and all cores, version + IPP line), otherwise the
+    C restatement oracle/farneback_ref.c built -O3 -march=native here (``kind: port``: 1 thread, and all cores with
+    OpenMP over pairs).  Also the max-abs end-point error of the GPU flow against that CPU result."""
     import numpy as np
     from oracle import oracle as O  # noqa: N812  (the checker; only ever used here, in tests and in smoke())
     O.build()
     hp, hn, gf = prevs[:k].cpu().numpy(), nexts[:k].cpu().numpy(), flow[:k].cpu().numpy()
     args = [getattr(p, a) for a in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
-    O.farneback(hp[0][:64, :64], hn[0][:64, :64], *args)  # load + warm the library
-    err = 0.0
-    t0 = time.perf_counter()
-    refs = [O.farneback(hp[i], hn[i], *args) for i in range(k)]
-    dt = time.perf_counter() - t0
-    for i in range(k):
-        err = max(err, float(np.abs(refs[i] - gf[i]).max()))
-    return {"cpu_baseline": {"value": round(k / dt, 4), "unit": "pairs/s", "cores": 1, "kind": "port",
-                             "sample": f"first {k} pairs of the timed batch, CPU oracle oracle/farneback_ref.c "
-                                       f"(gcc -O2, single thread; cv2 is not installed on this image)"},
-            "max_abs_epe_vs_oracle": err, "epe_tolerance": 1e-4}
+    model, logical, physical, usable = O.host_cpu()
+    base = {"unit": "pairs/s", "cpu_model": model, "logical_cores": logical, "physical_cores": physical,
+            "usable_cores": usable}
+    out = {}
+    try:
+        import cv2
+    except ImportError:
+        cv2 = None
+    if cv2 is not None:
+        info = cv2.getBuildInformation()
+        ipp = next((ln.strip() for ln in info.splitlines() if "IPP" in ln), "IPP: ?")
+        kw = dict(zip(("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags"), args))
+        res = {}
+        for nt in (1, usable):
+            cv2.setNumThreads(nt)
+            cv2.calcOpticalFlowFarneback(hp[0], hn[0], None, **kw)
+            t0 = time.perf_counter()
+            refs = [cv2.calcOpticalFlowFarneback(hp[i], hn[i], None, **kw) for i in range(k)]
+            res[nt] = k / (time.perf_counter() - t0)
+        err = max(float(np.abs(refs[i] - gf[i]).max()) for i in range(k))
+        out["cpu_baseline"] = dict(base, value=round(res[1], 4), cores=1, kind="reference",
+                                   value_all_cores=round(res[usable], 4), cores_all=usable,
+                                   sample=f"first {k} pairs of the timed batch, cv2 {cv2.__version__} ({ipp}), "
+                                          f"setNumThreads(1) and setNumThreads({usable})")
+        out["max_abs_epe_vs_cv2"] = err
+        err_o = max(float(np.abs(O.farneback(hp[i], hn[i], *args) - gf[i]).max()) for i in range(min(k, 2)))
+        out["max_abs_epe_vs_oracle"] = err_o
+        err = max(err, err_o)
+    else:
+        O.farneback_many(hp[:1, :64, :64], hn[:1, :64, :64], *args, n_threads=1)   # build + load + warm
+        t0 = time.perf_counter()
+        refs = O.farneback_many(hp, hn, *args, n_threads=1)
+        v1 = k / (time.perf_counter() - t0)
+        ka = max(k, min(4 * usable, prevs.shape[0]))            # all-cores leg: a few pairs per thread
+        hpa, hna = (hp, hn) if ka == k else (prevs[:ka].cpu().numpy(), nexts[:ka].cpu().numpy())
+        t0 = time.perf_counter()
+        O.farneback_many(hpa, hna, *args, n_threads=usable)
+        va = ka / (time.perf_counter() - t0)
+        err = max(float(np.abs(refs[i] - gf[i]).max()) for i in range(k))
+        out["cpu_baseline"] = dict(base, value=round(v1, 4), cores=1, kind="port",
+                                   value_all_cores=round(va, 4), cores_all=usable,
+                                   sample=f"first {k} pairs of the timed batch on 1 thread, first {ka} pairs on "
+                                          f"{usable} threads (OpenMP over pairs); CPU oracle oracle/farneback_ref.c "
+                                          f"built gcc -O3 -march=native -ffp-contract=off on this host; restatement, "
+                                          f"not OpenCV (cv2 is not importable on this image)")
+        out["max_abs_epe_vs_oracle"] = err
+    out["epe_tolerance"] = 1e-4
+    out["parity_ok"] = bool(err < 1e-4)
+    return out
 
 
 if __name__ == "__main__":

@@ -32,7 +32,8 @@ class FlowCall:
     params: object            # FarnebackParams
     prev: np.ndarray          # uint8 view of the frame (strided for ROI calls)
     next: np.ndarray
-    flow: np.ndarray = field(repr=False, default=None)   # float32 (h, w, 2) target: a view of the pair's canvas
+    flow: np.ndarray = field(repr=False, default=None)   # float32 (h, w, 2) target: a view of the pair's canvas ...
+    paste_to: np.ndarray = field(repr=False, default=None)   # ... or a private field pasted here afterwards (below)
 
     @property
     def shape(self):
@@ -92,9 +93,18 @@ def build_calls(name, stack, frames, n_pairs=None, cfg=None, with_full=True):
         _, memimg2 = gating.gating_maps(stack, i, cfg)
         canvas = np.zeros((h, w, 2), np.float32)
         canvases.append(canvas)
-        for (x0, y0, x1, y1) in roi_rects(memimg2, (h, w), cfg):
+        rects = roi_rects(memimg2, (h, w), cfg)
+        # FLAG 1 boxes of one pair may overlap; the reference pastes them one after the other, so the later component
+        # wins (seg.py:162).  Calls of a work list run concurrently: overlapping boxes get private fields that are
+        # pasted in the reference's order once the list is done; disjoint boxes are written into the canvas directly.
+        overlap = any(a[0] < b[2] and b[0] < a[2] and a[1] < b[3] and b[1] < a[3]
+                      for k, a in enumerate(rects) for b in rects[k + 1:])
+        for (x0, y0, x1, y1) in rects:
+            view = canvas[y0:y1, x0:x1]
             calls.append(FlowCall(name, i, "roi", (x0, y0, x1, y1), cfg.farneback_params, frames[i][y0:y1, x0:x1],
-                                  frames[i + 1][y0:y1, x0:x1], canvas[y0:y1, x0:x1]))
+                                  frames[i + 1][y0:y1, x0:x1],
+                                  np.empty((y1 - y0, x1 - x0, 2), np.float32) if overlap else view,
+                                  view if overlap else None))
         if with_full:
             calls.append(FlowCall(name, i, "full", (0, 0, w, h), cfg.farneback_params, frames[i], frames[i + 1],
                                   np.empty((h, w, 2), np.float32)))
@@ -136,7 +146,15 @@ def run_calls(calls, ctx=None, pairs_fn=None):
             farneback_pairs(pairs, params, flows, ctx=ctx)
         else:
             pairs_fn(pairs, params, flows)
+    paste(calls)
     return calls
+
+
+def paste(calls):
+    """Overlapping boxes: paste the private fields into their canvases in call order (later components win)."""
+    for c in calls:
+        if c.paste_to is not None:
+            c.paste_to[...] = c.flow
 
 
 def run_calls_one_by_one(calls, ctx=None, flow_fn=None):
@@ -145,4 +163,6 @@ def run_calls_one_by_one(calls, ctx=None, flow_fn=None):
     flow_fn = flow_fn or (lambda p, q, **kw: calcOpticalFlowFarneback(p, q, None, **kw, ctx=ctx))
     for c in calls:
         c.flow[...] = flow_fn(c.prev, c.next, **c.params.as_kwargs())
+        if c.paste_to is not None:
+            c.paste_to[...] = c.flow
     return calls

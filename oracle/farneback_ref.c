@@ -580,3 +580,39 @@ int nsof_ref_farneback_u8(const uint8_t* prev, ptrdiff_t prev_stride, const uint
     free(prevFlow); free(I); free(R[0]); free(R[1]); free(M);
     return rc;
 }
+
+/* Many independent pairs of one shape: the CPU-baseline legs of bench.py time this (one thread, and -- in the
+ * OpenMP build `make perf` -- all host cores, one pair per thread at a time: pairs are independent, exactly how
+ * the GPU path shards them).  prev/next: [n][height][stride]; flow: [n][height][width][2]. */
+int nsof_ref_farneback_u8_many(int n, const uint8_t* prev, const uint8_t* next, ptrdiff_t stride, ptrdiff_t pair_stride,
+                               int width, int height, float* flow, double pyr_scale, int levels, int winsize,
+                               int iterations, int poly_n, double poly_sigma, int flags, int n_threads)
+{
+    int rc_all = NSOF_REF_OK;
+    (void)n_threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1)
+#endif
+    for (int i = 0; i < n; i++) {
+        int rc = nsof_ref_farneback_u8(prev + (ptrdiff_t)i * pair_stride, stride, next + (ptrdiff_t)i * pair_stride, stride,
+                                       width, height, flow + (size_t)i * width * height * 2, (ptrdiff_t)width * 8,
+                                       pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags);
+        if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            rc_all = rc;
+        }
+    }
+    return rc_all;
+}
+
+/* 1 when this library was built with OpenMP (the all-cores leg needs the `perf` build). */
+int nsof_ref_has_openmp(void)
+{
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}

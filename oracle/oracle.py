@@ -96,6 +96,73 @@ def _u8(a):
     return a
 
 
+# ---------------------------------------------------------------- CPU-baseline build (bench.py cpu_baseline leg)
+def host_cpu():
+    """(model name, logical cores, physical cores) of this machine, from /proc/cpuinfo."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    cid = v
+                elif not k and pid is not None:
+                    phys.add((pid, cid))
+                    pid = cid = None
+            if pid is not None:
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    return model, logical, (len(phys) or logical), usable
+
+
+_perf = None
+
+
+def perf_lib():
+    """The -O3 -march=native -fopenmp build of the same sources, compiled ON the machine that times it (the file
+    name carries a tag of the host CPU so that a copy built elsewhere is never picked up).  Same arithmetic as the
+    checker build: -ffp-contract=off, no reassociation."""
+    global _perf
+    if _perf is None:
+        import hashlib
+        tag = hashlib.sha1(host_cpu()[0].encode()).hexdigest()[:10]
+        so = os.path.join(_HERE, "_build", f"libnsof_oracle_perf_{tag}.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "perf", f"PERF_OUT=_build/libnsof_oracle_perf_{tag}.so"])
+        l = C.CDLL(so)
+        l.nsof_ref_farneback_u8_many.restype = C.c_int
+        l.nsof_ref_farneback_u8_many.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int,
+                                                 C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_double, C.c_int, C.c_int]
+        l.nsof_ref_has_openmp.restype = C.c_int
+        _perf = l
+    return _perf
+
+
+def farneback_many(prevs, nexts, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags=0, n_threads=1):
+    """[n][H][W] uint8 x2 -> [n][H][W][2] float32 through the perf build, ``n_threads`` pairs at a time."""
+    prevs, nexts = np.ascontiguousarray(prevs, np.uint8), np.ascontiguousarray(nexts, np.uint8)
+    n, h, w = prevs.shape
+    flow = np.empty((n, h, w, 2), np.float32)
+    rc = perf_lib().nsof_ref_farneback_u8_many(n, prevs.ctypes.data, nexts.ctypes.data, w, w * h, w, h, flow.ctypes.data,
+                                               pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags,
+                                               int(n_threads))
+    _chk(rc, "farneback_many")
+    return flow
+
+
 # ---------------------------------------------------------------- Farneback
 def farneback(prev, nxt, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags=0):
     prev, nxt = _u8(prev), _u8(nxt)

@@ -53,7 +53,10 @@ def test_call_list_matches_reference_rectangles(nsof_lib, stacks):
         for c in by.get((name, "roi"), []):
             x0, y0, x1, y1 = c.rect
             assert c.prev.shape == (y1 - y0, x1 - x0) == c.flow.shape[:2]
-            assert np.shares_memory(c.flow, canvases[name][c.pair])
+            assert np.shares_memory(c.flow if c.paste_to is None else c.paste_to, canvases[name][c.pair])
+    # uavnew2 pair 0 has overlapping component boxes: private fields, pasted in order afterwards
+    assert all(c.paste_to is not None for c in by[("uavnew2", "roi")] if c.pair == 0)
+    assert all(c.paste_to is None for c in by[("grasp", "roi")])
     # parameter sets follow data/*/Parameters.txt
     from nsof.farneback import PARAMS_A, PARAMS_B, PARAMS_C
     want = {"grasp": PARAMS_A, "uavnew2": PARAMS_A, "autodriving": PARAMS_B, "uav": PARAMS_B, "tabletennis": PARAMS_C}
@@ -219,9 +222,12 @@ def test_config4_mixed_datasets_vs_oracle(nsof_lib, ctx, oracle, stacks):
         worst = max(worst, float(np.abs(c.flow - ref).max()))
     assert worst <= 1e-5, worst
     # the one-call-at-a-time pattern of the reference gives the same bits
-    again, _ = wl.mixed_workload(stacks, pairs_per_dataset=2)
+    again, canvases2 = wl.mixed_workload(stacks, pairs_per_dataset=2)
     wl.run_calls_one_by_one(again, ctx=ctx)
     assert all(np.array_equal(a.flow, b.flow) for a, b in zip(calls, again))
+    # ... and the same canvases, overlapping component boxes included (later components win)
+    for name in canvases:
+        assert all(np.array_equal(a, b) for a, b in zip(canvases[name], canvases2[name])), name
 
 
 @pytest.mark.gpu
