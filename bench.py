@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--params", choices=["A", "B", "C"], default="A")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--e2e-pairs", type=int, default=128,
+                    help="pairs of the host-to-host (PCIe-inclusive) leg, rank 0 at N=1 only; 0 = skip")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--mode", choices=["pairs", "sequence"], default="pairs",
                     help="pairs (headline): independent frame pairs; sequence: pairs+1 consecutive frames, the "
@@ -222,6 +224,8 @@ def main():
                         out[key]["traffic_source"] = ("estimated: algorithmic bytes x PMC ratio "
                                                       f"{ent['traffic_over_algorithmic']} from profiles/hbm_traffic.json "
                                                       "(rocprofv3 --pmc pass of scripts/stage_bench.py, see its _doc)")
+        if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
+            out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         print(json.dumps(out))
@@ -234,6 +238,47 @@ def main():
     ctx.close()
     if exit_code:
         sys.exit(exit_code)
+
+
+def e2e_leg(nsof, p, prevs, nexts, flow, k, local_rank):
+    """What a caller of the drop-in sees: frames in ordinary (pageable) host arrays in, flow in host memory out
+    (the reference times exactly this around its cv2 call, optical_flow_seg.py:202-206, 492-496).  k pairs through
+    nsof_farneback_u8_batch -- upload, compute and download of consecutive chunks overlap on three streams; the
+    flow fields are handed out in page-locked arrays (cv2 also returns arrays it allocated).  PCIe-inclusive: this is
+    NEVER the headline value."""
+    import numpy as np
+    h, w = prevs.shape[1:]
+    hp, hn = prevs[:k].cpu().numpy(), nexts[:k].cpu().numpy()
+    pairs = [(hp[i], hn[i]) for i in range(k)]
+    out = {}
+    with nsof.Context(local_rank) as c2:
+        pinned = [nsof.pinned_empty((h, w, 2), np.float32) for _ in range(k)]
+        nsof.farneback_pairs(pairs[:min(k, 64)], p, pinned[:min(k, 64)], ctx=c2)        # warm-up: staging, workspace
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            nsof.farneback_pairs(pairs, p, pinned, ctx=c2)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        same = bool(np.array_equal(pinned[0], flow[0].cpu().numpy()) and np.array_equal(pinned[k - 1], flow[k - 1].cpu().numpy()))
+        bytes_pair = 2 * h * w + 8 * h * w
+        out["e2e"] = {"value": round(k / best, 1), "unit": "pairs/s", "pairs": k,
+                      "path": "host numpy frames (pageable) -> nsof_farneback_u8_batch -> page-locked host flow arrays",
+                      "bytes_per_pair": bytes_pair, "d2h_GBps": round(k * 8 * h * w / best / 1e9, 2),
+                      "pcie_bound_pairs_per_s": round(55e9 / (8 * h * w), 1),
+                      "frac_of_pcie_bound": round((k / best) / (55e9 / (8 * h * w)), 3),
+                      "identical_to_device_resident": same}
+        kk = min(k, 32)                                    # pageable outputs: one more host copy per flow field
+        pageable = [np.empty((h, w, 2), np.float32) for _ in range(kk)]
+        nsof.farneback_pairs(pairs[:kk], p, pageable, ctx=c2)
+        t0 = time.perf_counter()
+        nsof.farneback_pairs(pairs[:kk], p, pageable, ctx=c2)
+        out["e2e"]["pageable_outputs_pairs_per_s"] = round(kk / (time.perf_counter() - t0), 1)
+        t0 = time.perf_counter()                           # one synchronous call per pair, the reference's pattern
+        for i in range(min(k, 16)):
+            nsof.calcOpticalFlowFarneback(hp[i], hn[i], None, **p.as_kwargs(), ctx=c2)
+        out["e2e"]["one_call_per_pair_pairs_per_s"] = round(min(k, 16) / (time.perf_counter() - t0), 1)
+    return out
 
 
 def cpu_leg(nsof, p, prevs, nexts, flow, k):
