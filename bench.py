@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--e2e-pairs", type=int, default=128,
                     help="pairs of the host-to-host (PCIe-inclusive) leg, rank 0 at N=1 only; 0 = skip")
+    ap.add_argument("--no-fast-leg", action="store_true",
+                    help="skip the extra leg that times the opt-in float polynomial expansion (NSOF_OPT_POLYEXP_F32)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--mode", choices=["pairs", "sequence"], default="pairs",
                     help="pairs (headline): independent frame pairs; sequence: pairs+1 consecutive frames, the "
@@ -183,11 +185,11 @@ def main():
         total_pairs = n * world * args.steps
         alg = algorithmic_bytes_per_pair(nsof, w, h, p)
 
-        def roof(kid):
+        def roof(kid, prof=prof, steps=args.steps):
             ms, launches = prof[kid]
             if not launches:
                 return None
-            bytes_total = alg[kid] * n * args.steps           # this rank's launches moved this many algorithmic bytes
+            bytes_total = alg[kid] * n * steps                # this rank's launches moved this many algorithmic bytes
             per_launch = bytes_total / launches
             gbs = bytes_total / (ms * 1e-3) / 1e9
             return {"kernel": _lib.load().nsof_kernel_name(kid).decode(), "bound": "hbm", "achieved": round(gbs, 1),
@@ -224,6 +226,9 @@ def main():
                         out[key]["traffic_source"] = ("estimated: algorithmic bytes x PMC ratio "
                                                       f"{ent['traffic_over_algorithmic']} from profiles/hbm_traffic.json "
                                                       "(rocprofv3 --pmc pass of scripts/stage_bench.py, see its _doc)")
+        if world == 1 and prof and args.mode == "pairs" and not args.no_fast_leg:
+            out.update(fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of=roof,
+                                        prof=prof, steps=max(2, min(args.steps, 5))))
         if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
             out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
@@ -238,6 +243,36 @@ def main():
     ctx.close()
     if exit_code:
         sys.exit(exit_code)
+
+
+def fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of, prof, steps):
+    """The opt-in tolerance mode of the north-star kernel (NSOF_OPT_POLYEXP_F32: float instead of double horizontal
+    accumulation): its roofline on the same batch, the whole-step rate with it, and how far the flow moves from the
+    default exact path (max-abs end-point difference over ALL pairs of the batch, computed on the device)."""
+    flow_fast = torch.empty_like(flow)
+    ctx.set_option(_lib.OPT_POLYEXP_F32, 1)
+    try:
+        nsof.farneback_batch(prevs, nexts, flow_fast, n, h, w, p, ctx=ctx)
+        torch.cuda.synchronize()
+        ctx.prof_enable(_lib.K_POLYEXP)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nsof.farneback_batch(prevs, nexts, flow_fast, n, h, w, p, ctx=ctx)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ms, launches = ctx.prof_collect(_lib.K_POLYEXP)
+        ctx.prof_enable()
+    finally:
+        ctx.set_option(_lib.OPT_POLYEXP_F32, 0)
+    prof = dict(prof)
+    prof[_lib.K_POLYEXP] = (ms, launches)
+    r = roof_of(_lib.K_POLYEXP, prof, steps)
+    diff = float((flow_fast - flow).abs().max().item())
+    per_pair = (flow_fast - flow).abs().amax(dim=(1, 2, 3))
+    return {"roofline_polyexp_fast": r, "fast_mode": {
+        "option": "NSOF_OPT_POLYEXP_F32=1 (opt-in; default path is the exact one)", "value": round(n * steps / dt, 2),
+        "unit": "pairs/s", "max_abs_epe_vs_exact_path": diff,
+        "pairs_above_1e-4": int((per_pair > 1e-4).sum().item()), "pairs": n}}
 
 
 def e2e_leg(nsof, p, prevs, nexts, flow, k, local_rank):

@@ -52,6 +52,14 @@ int nsof_abi_version(void);
 /* Launch on a caller-owned hipStream_t (e.g. torch's current stream); NULL -> own stream. */
 int nsof_set_stream(nsof_ctx* ctx, void* hip_stream);
 int nsof_synchronize(nsof_ctx* ctx);
+/* Options.  NSOF_OPT_POLYEXP_F32 (default 0): 1 = the polynomial-expansion kernel accumulates its horizontal
+ * moments in float instead of double -- faster, but NOT the reference library's arithmetic: the flow then differs
+ * from the default (exact) path by the end-point error DESIGN.md reports.  Applies to the uniform-shape entry points;
+ * the work-list entries always run the exact kernel.  New contexts take the default from the environment
+ * variable NSOF_POLYEXP_F32. */
+enum { NSOF_OPT_POLYEXP_F32 = 1 };
+int nsof_set_option(nsof_ctx* ctx, int option, int value);
+int nsof_get_option(const nsof_ctx* ctx, int option, int* value);
 
 /* ---- stage 2: Farneback --------------------------------------------------------------- */
 /* Same argument meaning and order as cv2.calcOpticalFlowFarneback (see call sites above).

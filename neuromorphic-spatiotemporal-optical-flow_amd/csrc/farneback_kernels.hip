@@ -631,7 +631,12 @@ struct PolyGeom {
     static constexpr int NV = (2 * NP + 4) / 4; // float4 per lane per moment row
 };
 
-template <int N, bool HET>
+// FAST (opt-in, nsof_set_option(NSOF_OPT_POLYEXP_F32)): the horizontal moments accumulate in float (fma) instead of
+// double -- NOT the reference library's arithmetic; results differ from the exact kernel in the last bits of R (see
+// DESIGN.md for the measured end-point error).  To keep the float sums small the image is taken relative to a
+// per-workgroup constant c (a constant image has zero derivatives, so the outputs do not depend on c; the
+// second-derivative outputs b1*ig03 + b5*ig33 cancel their two large terms, which is where float would lose most).
+template <int N, bool HET, bool FAST = false>
 __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, float* __restrict__ R, int W, int H,
                                                   int seg_rows, nsof_poly_taps tp,
                                                   const nsof_het_item* __restrict__ items)
@@ -675,19 +680,23 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
         return *reinterpret_cast<const float*>(Ib + ((unsigned)clampi(row, 0, H - 1) * (unsigned)W + (unsigned)xc) * 4u);
     };
 
+    // FAST: everything relative to the workgroup's first pixel
+    float cref = 0.f;
+    if constexpr (FAST)
+        cref = *reinterpret_cast<const float*>(Ib + ((unsigned)clampi(ys, 0, H - 1) * (unsigned)W + (unsigned)clampi(x0, 0, W - 1)) * 4u);
     // register window: win[j] = I[clamp(y - N + j)][xc]
     float win[2 * N + 1];
 #pragma unroll
-    for (int j = 0; j <= 2 * N; j++) win[j] = ld(ys - N + j);
+    for (int j = 0; j <= 2 * N; j++) win[j] = ld(ys - N + j) - cref;
     float pre[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) pre[q] = ld(ys + 1 + N + q);
+    for (int q = 0; q < 4; q++) pre[q] = ld(ys + 1 + N + q) - cref;
 
     int buf = 0;
     for (int y = ys; y < ye; y += 4, buf ^= 1) {
         float nxt[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) nxt[q] = ld(y + 5 + N + q);
+        for (int q = 0; q < 4; q++) nxt[q] = ld(y + 5 + N + q) - cref;
 
         // ---- vertical pass: 4 rows for this thread's column
 #pragma unroll
@@ -697,10 +706,16 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
             for (int k = 1; k <= N; k++) {
                 const float a = win[N - k], b = win[N + k];
                 float p = a + b;
-                t0 = t0 + tp.g[k] * p;
-                t2 = t2 + tp.xxg[k] * p;
-                p = b - a;
-                t1 = t1 + tp.xg[k] * p;
+                if constexpr (FAST) {
+                    t0 = fmaf(tp.g[k], p, t0);
+                    t2 = fmaf(tp.xxg[k], p, t2);
+                    t1 = fmaf(tp.xg[k], b - a, t1);
+                } else {
+                    t0 = t0 + tp.g[k] * p;
+                    t2 = t2 + tp.xxg[k] * p;
+                    p = b - a;
+                    t1 = t1 + tp.xg[k] * p;
+                }
             }
             sr[buf][0][q][tid] = t0;
             sr[buf][1][q][tid] = t1;
@@ -729,6 +744,66 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
             };
             double t03[4];  // b1 * ig03, shared by the xx and yy outputs
             float o0[4], o1[4], o2[4], o3[4], o4[4];
+            if constexpr (FAST) {
+                // float accumulation, taps in registers (xxg included), one moment row at a time
+                float fg[N + 1], fxg[N + 1], fxxg[N + 1];
+#pragma unroll
+                for (int k = 0; k <= N; k++) {
+                    fg[k] = (N > 7) ? ftap[0][k] : tp.g[k];
+                    fxg[k] = (N > 7) ? ftap[1][k] : tp.xg[k];
+                    fxxg[k] = tp.xxg[k];
+                }
+                const float i11 = (float)tp.ig11, i03 = (float)tp.ig03, i33 = (float)tp.ig33, i55 = (float)tp.ig55;
+                float t03f[4];
+                {
+                    float v[4 * G::NV];
+                    load_row(0, v);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c = G::NP + p;
+                        float a1 = v[c] * fg[0], a2 = 0.f, a4 = 0.f;
+#pragma unroll
+                        for (int k = 1; k <= N; k++) {
+                            const float hi = v[c + k], lo = v[c - k], sm = hi + lo;
+                            a1 = fmaf(sm, fg[k], a1);
+                            a4 = fmaf(sm, fxxg[k], a4);
+                            a2 = fmaf(hi - lo, fxg[k], a2);
+                        }
+                        t03f[p] = a1 * i03;
+                        o1[p] = a2 * i11;
+                        o3[p] = fmaf(a4, i33, t03f[p]);
+                    }
+                }
+                {
+                    float v[4 * G::NV];
+                    load_row(1, v);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c = G::NP + p;
+                        float a3 = v[c] * fg[0], a6 = 0.f;
+#pragma unroll
+                        for (int k = 1; k <= N; k++) {
+                            const float hi = v[c + k], lo = v[c - k];
+                            a3 = fmaf(hi + lo, fg[k], a3);
+                            a6 = fmaf(hi - lo, fxg[k], a6);
+                        }
+                        o0[p] = a3 * i11;
+                        o4[p] = a6 * i55;
+                    }
+                }
+                {
+                    float v[4 * G::NV];
+                    load_row(2, v);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c = G::NP + p;
+                        float a5 = v[c] * fg[0];
+#pragma unroll
+                        for (int k = 1; k <= N; k++) a5 = fmaf(v[c + k] + v[c - k], fg[k], a5);
+                        o2[p] = fmaf(a5, i33, t03f[p]);
+                    }
+                }
+            } else {
             // Large radii: 3(N+1) float + 2N double taps exceed the scalar register file (the spills cost more than
             // the arithmetic), so the horizontal pass takes its float taps from LDS into VGPRs as well.
             constexpr bool HT = N > 7;
@@ -793,6 +868,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
                     o2[p] = (float)(t03[p] + a5 * tp.ig33);
                 }
             }
+            }   // !FAST
             // channel 4 of the lane's 4 pixels: one 16-B store
             float* c4 = reinterpret_cast<float*>(Rb) + 4u * plane + opix;
             if ((W & 3) == 0) {
@@ -1197,7 +1273,11 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
-    hipLaunchKernelGGL((k_polyexp<N, false>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
+    if (ctx->opt_polyexp_f32)
+        hipLaunchKernelGGL((k_polyexp<N, false, true>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps,
+                           nullptr);
+    else
+        hipLaunchKernelGGL((k_polyexp<N, false>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
 }
 
 // Work-list twin: W, H are the largest level extents over the table, n_img = 2 * items.

@@ -136,6 +136,7 @@ extern "C" int nsof_create(int device, nsof_ctx** out)
         return nsof_set_error(nullptr, NSOF_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->stream = ctx->own_stream;
+    if (const char* e = getenv("NSOF_POLYEXP_F32")) ctx->opt_polyexp_f32 = (e[0] && e[0] != '0') ? 1 : 0;
     *out = ctx;
     return NSOF_OK;
 }
@@ -170,6 +171,26 @@ extern "C" int nsof_set_stream(nsof_ctx* ctx, void* s)
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
     return NSOF_OK;
+}
+
+extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (option == NSOF_OPT_POLYEXP_F32) {
+        ctx->opt_polyexp_f32 = value ? 1 : 0;
+        return NSOF_OK;
+    }
+    return nsof_set_error(ctx, NSOF_EINVAL, "unknown option %d", option);
+}
+
+extern "C" int nsof_get_option(const nsof_ctx* ctx, int option, int* value)
+{
+    if (!ctx || !value) return NSOF_EINVAL;
+    if (option == NSOF_OPT_POLYEXP_F32) {
+        *value = ctx->opt_polyexp_f32;
+        return NSOF_OK;
+    }
+    return NSOF_EINVAL;
 }
 
 extern "C" int nsof_synchronize(nsof_ctx* ctx)

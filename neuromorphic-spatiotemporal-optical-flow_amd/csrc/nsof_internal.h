@@ -24,6 +24,7 @@ struct nsof_ctx {
     hipStream_t own_stream = nullptr;
     unsigned prof_mask = 0;
     nsof_prof_slot prof[NSOF_K_COUNT];
+    int opt_polyexp_f32 = 0;   // NSOF_OPT_POLYEXP_F32
     char err[512] = {0};
     // reusable device workspace of the Farneback driver
     void* ws = nullptr;

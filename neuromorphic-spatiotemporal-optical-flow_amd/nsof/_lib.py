@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSOF_LIB", os.path.join(_HERE, "libnsof.so"))   # NSOF_LIB: A/B builds of the same ABI
 
+OPT_POLYEXP_F32 = 1
 NSOF_OK, NSOF_EINVAL, NSOF_ESHAPE, NSOF_EDEVICE, NSOF_ENOMEM, NSOF_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_SEGMENT, K_MORPH, K_REMAP, K_SSIM, K_COUNT = range(12)
 
@@ -29,6 +30,8 @@ SIGNATURES = {
     "nsof_abi_version": (_i, []),
     "nsof_set_stream": (_i, [_vp, _vp]),
     "nsof_synchronize": (_i, [_vp]),
+    "nsof_set_option": (_i, [_vp, _i, _i]),
+    "nsof_get_option": (_i, [_vp, _i, C.POINTER(_i)]),
     "nsof_farneback_u8": (_i, [_vp, _vp, _pd, _vp, _pd, _i, _i, _vp, _pd, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_batch_dev": (_i, [_vp, _i, _vp, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_sequence_dev": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),

@@ -47,6 +47,15 @@ class Context:
         """Launch on a caller-owned HIP stream (``torch.cuda.current_stream().cuda_stream``); None = own."""
         self.check(self._lib.nsof_set_stream(self.ptr, C.c_void_p(stream) if stream else None), "set_stream")
 
+    def set_option(self, option, value):
+        """``nsof_set_option``: e.g. ``ctx.set_option(_lib.OPT_POLYEXP_F32, 1)`` (float polynomial expansion, opt-in)."""
+        self.check(self._lib.nsof_set_option(self.ptr, int(option), int(value)), "set_option")
+
+    def get_option(self, option):
+        v = C.c_int()
+        self.check(self._lib.nsof_get_option(self.ptr, int(option), C.byref(v)), "get_option")
+        return v.value
+
     def synchronize(self):
         self.check(self._lib.nsof_synchronize(self.ptr), "synchronize")
 
