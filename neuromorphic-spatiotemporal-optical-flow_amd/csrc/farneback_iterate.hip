@@ -347,8 +347,29 @@ struct PCGeom {
     static constexpr int RL = 2 * MH + 6;                   // ring rows: window 2m+1, the leaving row, 2 being
                                                             // consumed next, 2 being produced
     static constexpr int SW = (COLS - 2 * MH) & ~1;         // output columns per block
-    static constexpr size_t SMEM = sizeof(double) * 4 * 5 * COLS + sizeof(float) * RL * 5 * COLS;
+    // Column sums of one (row, plane) in LDS.  HIER (windows of 5 columns and more): instead of the COLS sums v[i]
+    // themselves, the even columns A[j] = v[2j], the pair sums P[j] = v[2j] + v[2j+1] and the quad sums
+    // Q[j] = P[2j] + P[2j+1] (+ one 0.0) -- a (2m+1)-window sum then takes about m/2 + 5 LDS reads instead of
+    // 2m + 3.  The row sums are bound by LDS bandwidth (every column sum used to be read 2m+1 times by 4 waves at
+    // once, right after the barrier), see DESIGN.md 5.1.
+    static constexpr bool HIER = MH >= 2;
+    static constexpr int HALF = COLS / 2, ZIDX = COLS + COLS / 4;
+    static constexpr int SVW = HIER ? COLS + COLS / 4 + 2 : COLS;   // doubles per (row, plane)
+    static constexpr size_t SV_BYTES = sizeof(double) * 4 * 5 * SVW;
+    static constexpr size_t SMEM = SV_BYTES + sizeof(float) * RL * 5 * COLS;
 };
+
+// A double from another lane of the same quad (DPP quad_perm: full-rate VALU moves, no LDS crossbar).
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_LANE_PLUS1 = 0xF5;   // quad_perm:[1,1,3,3]: even lanes read their right neighbour
+constexpr int DPP_LANE_PLUS2 = 0xEE;   // quad_perm:[2,3,2,3]: lanes 0,1 of a quad read lanes 2,3
 
 // Producer group G owns row G of every 2-row step: stream index i(t) = 2t + m + G.  It produces M for step t
 // from the loads in slot J = t & 3, then refills that slot with step t+4 (4 rows = 4 steps of loads in flight
@@ -416,12 +437,16 @@ __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Pla
 // Fout / fpitch: the output field and its row pitch in float2 units (W for the dense batch layout; the work-list
 // path writes the last iteration straight into the caller's possibly strided field).
 template <int MH, int COLS, typename FS>
-__device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
-                                              const Planes& R1, const FS& F, float2* Fout, size_t fpitch, int W, int H,
-                                              int x0, int xc, int col, int nsteps, double scale)
+__device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*sv)[5][PCGeom<MH, COLS>::SVW],
+                                              const Planes& R0, const Planes& R1, const FS& F, float2* Fout,
+                                              size_t fpitch, int W, int H, int x0, int xc, int col, int nsteps,
+                                              double scale)
 {
     using G = PCGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
+    constexpr bool HIER = G::HIER;
+    constexpr int HALF = G::HALF, ZIDX = G::ZIDX;
+    if (HIER && col < 20) sv[col / 5][col % 5][ZIDX] = 0.0;   // the "nothing to add" slot of every (row, plane)
     double vs[5];
 #ifdef NSOF_CONSUMER_PRIO
     __builtin_amdgcn_s_setprio(NSOF_CONSUMER_PRIO);   // experiment: the consumers' dependent chain first
@@ -463,11 +488,33 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
 #endif
 #pragma unroll
         for (int q = 0; q < 2; q++) {
+            if constexpr (HIER) {
+                double pr[5], qd[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
-                vs[c] += (double)d;
-                sv[2 * buf + q][c][col] = vs[c];
+                for (int c = 0; c < 5; c++) {
+                    const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
+                    vs[c] += (double)d;
+                    pr[c] = vs[c] + dpp_quad<DPP_LANE_PLUS1>(vs[c]);   // even lanes: v[col] + v[col+1]
+                    qd[c] = pr[c] + dpp_quad<DPP_LANE_PLUS2>(pr[c]);   // lanes 0 mod 4: v[col..col+3]
+                }
+                if ((col & 1) == 0) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        sv[2 * buf + q][c][col >> 1] = vs[c];
+                        sv[2 * buf + q][c][HALF + (col >> 1)] = pr[c];
+                    }
+                }
+                if ((col & 3) == 0) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) sv[2 * buf + q][c][2 * HALF + (col >> 2)] = qd[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
+                    vs[c] += (double)d;
+                    sv[2 * buf + q][c][col] = vs[c];
+                }
             }
             slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
             slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
@@ -488,12 +535,38 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*
         }
 #else
         if (2 * t < SW && yo < H && xo < W) {
-            const double (*svr)[COLS] = sv[2 * buf + hrow];
-            double g[5];
+            const double (*svr)[G::SVW] = sv[2 * buf + hrow];
+            double g[5], g1[5];
             float2 o[2];
+            if constexpr (HIER) {
+                // window of pixel 2t: columns 2t .. 2t+2m = pairs t .. t+m-1 and the even column 2(t+m);
+                // pixel 2t+1: the same minus column 2t plus column 2t+2m+1 (= P[t+m] - A[t+m]).
+                // The m pairs: an odd first pair and / or an odd last pair alone, quads in between.
+                const int s0 = t + (t & 1), r = t + MH - s0, nq = r >> 1;
+                constexpr int NQMAX = MH / 2;
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    double a;
+                    if constexpr (MH & 1) {   // exactly one lone pair: the first (t odd) or the last (t even)
+                        a = svr[c][HALF + ((t & 1) ? t : t + MH - 1)];
+                    } else {                  // none (t even) or both (t odd)
+                        a = svr[c][(t & 1) ? HALF + t : ZIDX] + svr[c][(t & 1) ? HALF + t + MH - 1 : ZIDX];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQMAX; q++) a += svr[c][(q < nq) ? 2 * HALF + (s0 >> 1) + q : ZIDX];
+                    const double am = svr[c][t + MH];
+                    g[c] = a + am;
+                    g1[c] = g[c] - svr[c][t] + (svr[c][HALF + t + MH] - am);
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                if (p == 0) {
+                if constexpr (HIER) {
+                    if (p == 1) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) g[c] = g1[c];
+                    }
+                } else if (p == 0) {
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         double a = 0;
@@ -543,8 +616,9 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
 {
     constexpr int SW = PCGeom<MH, COLS>::SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
-    double (*sv)[5][COLS] = reinterpret_cast<double (*)[5][COLS]>(smem_pc);   // [2 buffers x 2 rows][5][COLS]
-    float (*mring)[5][COLS] = reinterpret_cast<float (*)[5][COLS]>(smem_pc + sizeof(double) * 4 * 5 * COLS);  // [RL]
+    using PG = PCGeom<MH, COLS>;
+    double (*sv)[5][PG::SVW] = reinterpret_cast<double (*)[5][PG::SVW]>(smem_pc);   // [2 buffers x 2 rows][5][SVW]
+    float (*mring)[5][COLS] = reinterpret_cast<float (*)[5][COLS]>(smem_pc + PG::SV_BYTES);  // [RL]
 
     const int tid = threadIdx.x, col = tid % COLS;
     const int role = __builtin_amdgcn_readfirstlane(tid / COLS);   // wave-uniform: 0 consumer, 1/2 producers
