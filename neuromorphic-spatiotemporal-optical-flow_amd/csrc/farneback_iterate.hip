@@ -437,12 +437,12 @@ __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Pla
 // Fout / fpitch: the output field and its row pitch in float2 units (W for the dense batch layout; the work-list
 // path writes the last iteration straight into the caller's possibly strided field).
 template <int MH, int COLS, typename FS>
-__device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], double (*sv)[5][PCGeom<MH, COLS>::SVW],
-                                              const Planes& R0, const Planes& R1, const FS& F, float2* Fout,
-                                              size_t fpitch, int W, int H, int x0, int xc, int col, int nsteps,
-                                              double scale)
+__device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], void* sv_raw, const Planes& R0,
+                                              const Planes& R1, const FS& F, float2* Fout, size_t fpitch, int W, int H,
+                                              int x0, int xc, int col, int nsteps, double scale)
 {
     using G = PCGeom<MH, COLS>;
+    double (*sv)[5][G::SVW] = reinterpret_cast<double (*)[5][G::SVW]>(sv_raw);   // [2 buffers x 2 rows][5][SVW]
     constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
     constexpr bool HIER = G::HIER;
     constexpr int HALF = G::HALF, ZIDX = G::ZIDX;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
     constexpr int SW = PCGeom<MH, COLS>::SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
     using PG = PCGeom<MH, COLS>;
-    double (*sv)[5][PG::SVW] = reinterpret_cast<double (*)[5][PG::SVW]>(smem_pc);   // [2 buffers x 2 rows][5][SVW]
+    void* sv = smem_pc;                                                              // [2 buffers x 2 rows][5][SVW] doubles
     float (*mring)[5][COLS] = reinterpret_cast<float (*)[5][COLS]>(smem_pc + PG::SV_BYTES);  // [RL]
 
     const int tid = threadIdx.x, col = tid % COLS;
