@@ -19,6 +19,7 @@
 // HBM traffic per pixel per iteration: R0 20 + R1 ~20 + flow 8 read, flow 8 written = 56 B (+ halo).
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "nsof_internal.h"
 
@@ -352,7 +353,11 @@ struct PCGeom {
     // Q[j] = P[2j] + P[2j+1] (+ one 0.0) -- a (2m+1)-window sum then takes about m/2 + 5 LDS reads instead of
     // 2m + 3.  The row sums are bound by LDS bandwidth (every column sum used to be read 2m+1 times by 4 waves at
     // once, right after the barrier), see DESIGN.md 5.1.
+#ifdef NSOF_NO_HIER   // A/B build: the plain layout (every column sum read 2m+1 times)
+    static constexpr bool HIER = false;
+#else
     static constexpr bool HIER = MH >= 2;
+#endif
     static constexpr int HALF = COLS / 2, ZIDX = COLS + COLS / 4;
     static constexpr int SVW = HIER ? COLS + COLS / 4 + 2 : COLS;   // doubles per (row, plane)
     static constexpr size_t SV_BYTES = sizeof(double) * 4 * 5 * SVW;
@@ -375,8 +380,8 @@ constexpr int DPP_LANE_PLUS2 = 0xEE;   // quad_perm:[2,3,2,3]: lanes 0,1 of a qu
 // from the loads in slot J = t & 3, then refills that slot with step t+4 (4 rows = 4 steps of loads in flight
 // per thread).  The gather addresses depend on the flow, so the flow of step t+4 was itself fetched four
 // windows earlier (fl[J]); a one-window flow lookahead makes every window wait for a full memory latency.
-template <int MH, int COLS, int G, int J, typename FS>
-__device__ __forceinline__ void produce_row(RowIn (&in)[4], typename FS::Raw (&fl)[4], float (*mring)[5][COLS],
+template <int MH, int COLS, int G, int J, int NS, typename FS>
+__device__ __forceinline__ void produce_row(RowIn (&in)[NS], typename FS::Raw (&fl)[NS], float (*mring)[5][COLS],
                                             const Planes& R0,
                                             const Planes& R1, const FS& F, int W, int H, int xc, int col, int t)
 {
@@ -390,53 +395,59 @@ __device__ __forceinline__ void produce_row(RowIn (&in)[4], typename FS::Raw (&f
     const int slot = (i + MH + 1) % RL;      // stream index -MH-1 (first replicated row) lives in slot 0
 #pragma unroll
     for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
-    issue_row(in[J], R0, R1, W, H, xc, min(i + 8, H - 1), F.resolve(fl[J]));
-    fl[J] = F.fetch(min(i + 16, H - 1));
+    issue_row(in[J], R0, R1, W, H, xc, min(i + 2 * NS, H - 1), F.resolve(fl[J]));   // step t + NS
+    fl[J] = F.fetch(min(i + 4 * NS, H - 1));                                         // flow of step t + 2 NS
 }
 
 // Producer waves of group G: their own loop, with exactly the same barrier sequence as the consumers.
-template <int MH, int COLS, int G, typename FS>
+// NS = steps of loads in flight per thread (4 in the 12-wave layout; 3 in the 16-wave layout, whose 4 waves per
+// SIMD leave 128 VGPRs per wave).
+template <int MH, int COLS, int G, int NS, typename FS>
 __device__ __forceinline__ void producer_loop(float (*mring)[5][COLS], const Planes& R0, const Planes& R1,
                                               const FS& F, int W, int H, int xc, int col, int nsteps)
 {
-    RowIn in[4];
-    typename FS::Raw fl[4];
+    RowIn in[NS];
+    typename FS::Raw fl[NS];
 #ifdef NSOF_PRODUCER_PRIO
     __builtin_amdgcn_s_setprio(NSOF_PRODUCER_PRIO);   // experiment: issue the gather ahead of the consumers' arithmetic
 #endif
     auto flowAt = [&](int r) { return F.at(r); };
 #pragma unroll
-    for (int j = 0; j < 4; j++) {   // steps 0..3 in flight
+    for (int j = 0; j < NS; j++) {   // steps 0..NS-1 in flight
         const int r = min(2 * j + MH + G, H - 1);
         issue_row(in[j], R0, R1, W, H, xc, r, flowAt(r));
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) fl[j] = F.fetch(min(2 * (j + 4) + MH + G, H - 1));   // flows of steps 4..7
+    for (int j = 0; j < NS; j++) fl[j] = F.fetch(min(2 * (j + NS) + MH + G, H - 1));   // flows of steps NS..2NS-1
     // Barrier sequence (identical in all roles): B_init, then B(s) for s = 0..nsteps-1.
     //   before B_init            step 0 is produced
     //   between B_init and B(0)  step 1                              (consumers: column sums of step 0)
     //   between B(s) and B(s+1)  step s+2                            (consumers: row sums + solve of step s,
     //                                                                 column sums of step s+1)
-    produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
+    produce_row<MH, COLS, G, 0, NS>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
     __syncthreads();
-    produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
-    for (int sb = 0; sb < nsteps; sb += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int s = sb + u;
-            if (s >= nsteps) break;
-            __syncthreads();
-            if (u == 0) produce_row<MH, COLS, G, 2>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
-            if (u == 1) produce_row<MH, COLS, G, 3>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
-            if (u == 2) produce_row<MH, COLS, G, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
-            if (u == 3) produce_row<MH, COLS, G, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
+    produce_row<MH, COLS, G, 1, NS>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
+    auto one = [&](auto uc, int s) {   // step s + 2 uses slot (s + 2) % NS; s = sb + u with sb a multiple of NS
+        constexpr int u = decltype(uc)::value;
+        produce_row<MH, COLS, G, (u + 2) % NS, NS>(in, fl, mring, R0, R1, F, W, H, xc, col, s + 2);
+    };
+    for (int sb = 0; sb < nsteps; sb += NS) {
+        if (sb < nsteps) { __syncthreads(); one(std::integral_constant<int, 0>{}, sb); }
+        if (sb + 1 < nsteps) { __syncthreads(); one(std::integral_constant<int, 1>{}, sb + 1); }
+        if (sb + 2 < nsteps) { __syncthreads(); one(std::integral_constant<int, 2>{}, sb + 2); }
+        if constexpr (NS > 3) {
+            if (sb + 3 < nsteps) { __syncthreads(); one(std::integral_constant<int, 3>{}, sb + 3); }
         }
     }
 }
 
 // Fout / fpitch: the output field and its row pitch in float2 units (W for the dense batch layout; the work-list
 // path writes the last iteration straight into the caller's possibly strided field).
-template <int MH, int COLS, typename FS>
+// DO_COL / DO_SOLVE: the consumer's two halves.  Both true: one wave group does them one after the other (12-wave
+// layout).  In the 16-wave layout they are two wave groups working side by side: between B(s) and B(s+1) the
+// column-sum group forms the sums of step s+1 (into the other sv buffer) while the solve group consumes those of
+// step s -- same data flow and barrier sequence, half the dependent chain per wave and barrier interval.
+template <int MH, int COLS, bool DO_COL, bool DO_SOLVE, typename FS>
 __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], void* sv_raw, const Planes& R0,
                                               const Planes& R1, const FS& F, float2* Fout, size_t fpitch, int W, int H,
                                               int x0, int xc, int col, int nsteps, double scale)
@@ -446,13 +457,13 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], void* sv_
     constexpr int RL = G::RL, SW = G::SW, HT = COLS / 2;   // HT threads per output row, 2 pixels each
     constexpr bool HIER = G::HIER;
     constexpr int HALF = G::HALF, ZIDX = G::ZIDX;
-    if (HIER && col < 20) sv[col / 5][col % 5][ZIDX] = 0.0;   // the "nothing to add" slot of every (row, plane)
+    if (HIER && DO_COL && col < 20) sv[col / 5][col % 5][ZIDX] = 0.0;   // the "nothing to add" slot of every (row, plane)
     double vs[5];
 #ifdef NSOF_CONSUMER_PRIO
     __builtin_amdgcn_s_setprio(NSOF_CONSUMER_PRIO);   // experiment: the consumers' dependent chain first
 #endif
     auto flowAt = [&](int r) { return F.at(r); };
-    {
+    if constexpr (DO_COL) {
         // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
         // ring slot of stream index i is (i + m + 1) % RL.
         RowIn t;
@@ -520,11 +531,16 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], void* sv_
             slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
         }
     };
-    column_sums(0);
+    if constexpr (DO_COL) column_sums(0);
     for (int s = 0; s < nsteps; s++) {
         __syncthreads();   // B(s): column sums of step s visible; rows of step s+1 are in the ring
         const int buf = s & 1;
         const int yo = 2 * s + hrow, xo = x0 + 2 * t;
+        if constexpr (!DO_SOLVE) {
+            (void)xo; (void)yo;
+            if (s + 1 < nsteps) column_sums(buf ^ 1);
+            continue;
+        }
 #if defined(NSOF_ABL) && (NSOF_ABL == 4 || NSOF_ABL == 6)
         (void)xo; (void)yo;
 #elif defined(NSOF_ABL) && NSOF_ABL == 2   // timing-only build: no row sums / solve
@@ -594,7 +610,8 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], void* sv_
         }
 #endif
         // column sums of the next step go to the other buffer: no barrier needed in between
-        if (s + 1 < nsteps) column_sums(buf ^ 1);
+        if constexpr (DO_COL)
+            if (s + 1 < nsteps) column_sums(buf ^ 1);
     }
 }
 
@@ -607,8 +624,9 @@ struct UpsArgs {
 // HET: work-list launch -- blockIdx.z indexes a device table of items of different shapes (nsof_het_item): R0b is
 // the level's expansion buffer, flow_in / flow_out the level's flow buffers (item fields at offF), and with
 // het_final the flow goes to the item's own output field instead.
-template <int MH, int COLS, bool UPS, bool HET = false>
-__global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict__ R0b, const float* __restrict__ R1b,
+// SPLIT: 16 waves per strip (solve | column sums | producers A | producers B) instead of 12.
+template <int MH, int COLS, bool UPS, bool HET = false, bool SPLIT = false>
+__global__ __launch_bounds__((SPLIT ? 4 : 3) * COLS) void k_iterate_pc(const float* __restrict__ R0b, const float* __restrict__ R1b,
                                                      size_t pair_stride, const float* __restrict__ flow_in,
                                                      float* __restrict__ flow_out, int W, int H, int block_size,
                                                      UpsArgs ups, const nsof_het_item* __restrict__ items = nullptr,
@@ -683,13 +701,24 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_pc(const float* __restrict
     float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)pair * plane;
     const int nsteps = (H + 1) / 2;
     // Each role runs its own loop; all three execute one barrier before the loop and two per step.
-    if (role == 0)
-        consumer_loop<MH, COLS>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps,
-                                1. / (block_size * block_size));
-    else if (role == 1)
-        producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
-    else
-        producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
+    const double scale = 1. / (block_size * block_size);
+    if constexpr (SPLIT) {
+        if (role == 0)
+            consumer_loop<MH, COLS, false, true>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, scale);
+        else if (role == 1)
+            consumer_loop<MH, COLS, true, false>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, scale);
+        else if (role == 2)
+            producer_loop<MH, COLS, 0, 3>(mring, R0, R1, F, W, H, xc, col, nsteps);
+        else
+            producer_loop<MH, COLS, 1, 3>(mring, R0, R1, F, W, H, xc, col, nsteps);
+    } else {
+        if (role == 0)
+            consumer_loop<MH, COLS, true, true>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, scale);
+        else if (role == 1)
+            producer_loop<MH, COLS, 0, 4>(mring, R0, R1, F, W, H, xc, col, nsteps);
+        else
+            producer_loop<MH, COLS, 1, 4>(mring, R0, R1, F, W, H, xc, col, nsteps);
+    }
 }
 
 // > 64 KB of dynamic LDS needs the opt-in attribute, once per (kernel instance, device); contexts of several
@@ -711,8 +740,17 @@ int launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float
                         const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
     using G = PCGeom<MH, COLS>;
-    if (int rc = lds_opt_in(ctx, k_iterate_pc<MH, COLS, UPS>, G::SMEM)) return rc;
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
+    if constexpr (!UPS && COLS == 256) {
+        static const bool split = getenv("NSOF_ITER_SPLIT") != nullptr;   // 16-wave layout (A/B)
+        if (split) {
+            if (int rc = lds_opt_in(ctx, k_iterate_pc<MH, COLS, false, false, true>, G::SMEM)) return rc;
+            hipLaunchKernelGGL((k_iterate_pc<MH, COLS, false, false, true>), grid, dim3(4 * COLS), G::SMEM, ctx->stream,
+                               R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups, nullptr, 0);
+            return NSOF_OK;
+        }
+    }
+    if (int rc = lds_opt_in(ctx, k_iterate_pc<MH, COLS, UPS>, G::SMEM)) return rc;
     hipLaunchKernelGGL((k_iterate_pc<MH, COLS, UPS>), grid, dim3(3 * COLS), G::SMEM, ctx->stream, R0, R1, pair_stride,
                        flow_in, flow_out, W, H, winsize, ups);
     return NSOF_OK;
