@@ -735,6 +735,265 @@ int lds_opt_in(nsof_ctx* ctx, K kernel, size_t bytes)
     return NSOF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Quad-row variant: the same role-specialised walker, FOUR rows per step.
+//
+// A step of the 2-row kernel above lasts about as long whatever it carries (measured: ~1.5 us for 128- and for
+// 256-column strips): every wave's work per step is one dependent chain -- LDS round trips, the double-precision
+// solve, a gather's address arithmetic -- and a CU holds only the 12 waves of one strip (the 100 KB ring), so VALU,
+// LDS and the vector L1 all sit at 35-55 % busy while the waves wait on their own previous instruction.  More
+// independent work per chain is what fills them: here a step moves 4 rows.
+//   waves 0-3   consumers: column sums of 4 rows (thread <-> column), then row sums + solve, thread <-> 4 adjacent
+//               pixels of one row (first pixel summed directly, the next three sliding)
+//   waves 4-7 / 8-11  producers A / B: rows 0,1 / 2,3 of every step, the loads of their next two steps in flight
+// The column sums are single-buffered (4 rows x 5 planes x 256 doubles = 40 KB) so that the ring of 2m+9 rows of M
+// (23 x 5 KB at winsize 15) still fits the 160 KB of LDS: two barriers per step (column sums visible / consumed),
+// i.e. as many per row as before.  Producers write the first row of step t+1 while the consumers form the column
+// sums of step t, and its second row while they solve; the slots those rows overwrite left the window long before.
+// Arithmetic per pixel and its order are those of k_iterate_pc (pixels 4k+2, 4k+3 of a row reach their row sums by
+// sliding instead of by a direct sum: same double-precision values up to their last bit).
+// ---------------------------------------------------------------------------------------------
+template <int MH>
+struct QGeom {
+    static constexpr int COLS = 256, RB = 4;
+    static constexpr int RL = 2 * MH + 1 + 2 * RB;
+    static constexpr int SW = (COLS - 2 * MH) & ~3;         // a solve thread owns 4 whole pixels
+    static constexpr size_t SV_BYTES = sizeof(double) * RB * 5 * COLS;
+    static constexpr size_t SMEM = SV_BYTES + sizeof(float) * RL * 5 * COLS;
+};
+
+template <int MH, int GP, int TS, int RR>
+__device__ __forceinline__ void q_produce(RowIn (&in)[2][2], FlowSrc<false>::Raw (&fl)[2][2], float (*mring)[5][256],
+                                          const Planes& R0, const Planes& R1, const FlowSrc<false>& F, int W, int H, int xc,
+                                          int col, int t)
+{
+    constexpr int RL = QGeom<MH>::RL;
+    const int i = 4 * t + MH + 2 * GP + RR;                  // stream index of this row
+    float Mn[5];
+    matrix_from(in[TS][RR], xc, min(i, H - 1), W, H, Mn);
+    const int slot = (i + MH + 1) % RL;
+#pragma unroll
+    for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
+    issue_row(in[TS][RR], R0, R1, W, H, xc, min(i + 8, H - 1), F.resolve(fl[TS][RR]));   // the same row of step t+2
+    fl[TS][RR] = F.fetch(min(i + 16, H - 1));                                            // its flow for step t+4
+}
+
+template <int MH, int GP>
+__device__ __forceinline__ void q_producer_loop(float (*mring)[5][256], const Planes& R0, const Planes& R1,
+                                                const FlowSrc<false>& F, int W, int H, int xc, int col, int nsteps)
+{
+    RowIn in[2][2];
+    FlowSrc<false>::Raw fl[2][2];
+#pragma unroll
+    for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = min(4 * ts + MH + 2 * GP + rr, H - 1);
+            issue_row(in[ts][rr], R0, R1, W, H, xc, r, F.at(r));
+        }
+#pragma unroll
+    for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) fl[ts][rr] = F.fetch(min(4 * (ts + 2) + MH + 2 * GP + rr, H - 1));
+    // Barriers (all roles alike): B_init, then B1(t), B2(t) for every step t.
+    //   before B_init          both rows of step 0
+    //   B_init .. B1(0)        first row of step 1            (consumers: column sums of step 0)
+    //   B1(t) .. B2(t)         second row of step t+1         (consumers: row sums + solve of step t)
+    //   B2(t) .. B1(t+1)       first row of step t+2          (consumers: column sums of step t+1)
+    q_produce<MH, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
+    q_produce<MH, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
+    __syncthreads();
+    q_produce<MH, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
+    for (int tb = 0; tb < nsteps; tb += 2) {
+        __syncthreads();                                                             // B1(tb)
+        q_produce<MH, GP, 1, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 1);
+        __syncthreads();                                                             // B2(tb)
+        q_produce<MH, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
+        if (tb + 1 >= nsteps) break;
+        __syncthreads();                                                             // B1(tb+1)
+        q_produce<MH, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
+        __syncthreads();                                                             // B2(tb+1)
+        q_produce<MH, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 3);
+    }
+}
+
+template <int MH>
+__device__ __forceinline__ void q_consumer_loop(float (*mring)[5][256], double (*sv)[5][256], const Planes& R0,
+                                                const Planes& R1, const FlowSrc<false>& F, float2* Fout, size_t fpitch,
+                                                int W, int H, int x0, int xc, int col, int nsteps, double scale)
+{
+    using G = QGeom<MH>;
+    constexpr int RL = G::RL, SW = G::SW;
+    double vs[5];
+    {
+        // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
+        // ring slot of stream index i is (i + m + 1) % RL.
+        RowIn t;
+        float M0[5];
+        issue_row(t, R0, R1, W, H, xc, 0, F.at(0));
+        matrix_from(t, xc, 0, W, H, M0);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            vs[c] = (double)(M0[c] * (float)(MH + 2));   // float product, as "srow0[x]*(m+2)"
+#pragma unroll
+            for (int j = 0; j <= MH + 1; j++) mring[j][c][col] = M0[c];   // stream indices -m-1 .. 0
+        }
+#pragma unroll
+        for (int i = 1; i < MH; i++) {
+            float Mi[5];
+            const int r = min(i, H - 1);
+            issue_row(t, R0, R1, W, H, xc, r, F.at(r));
+            matrix_from(t, xc, r, W, H, Mi);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c] += (double)Mi[c];
+                mring[i + MH + 1][c][col] = Mi[c];
+            }
+        }
+    }
+    __syncthreads();   // B_init: step 0 is in the ring
+    const int hrow = col >> 6, t4 = col & 63;   // solve phase: 64 threads per row, 4 pixels each
+    int slot_new = (2 * MH + 1) % RL;           // stream index m    -> slot 2m+1
+    int slot_old = 0;                           // stream index -m-1 -> slot 0
+    for (int t = 0; t < nsteps; t++) {
+        // column sums: four more rows enter the window of this thread's column
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
+                vs[c] += (double)d;
+                sv[q][c][col] = vs[c];
+            }
+            slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
+            slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
+        }
+        __syncthreads();   // B1(t): column sums of step t visible
+        const int yo = 4 * t + hrow, xo = x0 + 4 * t4;
+        if (4 * t4 < SW && yo < H && xo < W) {
+            const double (*svr)[256] = sv[hrow];
+            double g[5];
+            float2 o[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                if (p == 0) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        double a = 0;
+#pragma unroll
+                        for (int j = 0; j <= 2 * MH; j++) a += svr[c][4 * t4 + j];
+                        g[c] = a;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) g[c] += svr[c][4 * t4 + p + 2 * MH] - svr[c][4 * t4 + p - 1];
+                }
+                const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
+                const double h1 = g[3] * scale, h2 = g[4] * scale;
+                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
+                o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+            float2* dst = Fout + (size_t)yo * fpitch + xo;
+            if (xo + 3 < W && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                nsof_store_stream4(reinterpret_cast<float*>(dst), o[0].x, o[0].y, o[1].x, o[1].y);
+                nsof_store_stream4(reinterpret_cast<float*>(dst + 2), o[2].x, o[2].y, o[3].x, o[3].y);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    if (xo + p < W) dst[p] = o[p];
+            }
+        }
+        __syncthreads();   // B2(t): column sums consumed, the buffer may be rewritten
+    }
+}
+
+template <int MH, bool HET>
+__global__ __launch_bounds__(768) void k_iterate_q(const float* __restrict__ R0b, const float* __restrict__ R1b,
+                                                    size_t pair_stride, const float* __restrict__ flow_in,
+                                                    float* __restrict__ flow_out, int W, int H, int block_size,
+                                                    const nsof_het_item* __restrict__ items, int het_final)
+{
+    using G = QGeom<MH>;
+    constexpr int SW = G::SW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+    double (*sv)[5][256] = reinterpret_cast<double (*)[5][256]>(smem_q);                       // [4 rows]
+    float (*mring)[5][256] = reinterpret_cast<float (*)[5][256]>(smem_q + G::SV_BYTES);        // [RL]
+    const int tid = threadIdx.x, col = tid & 255;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: 0 consumers, 1/2 producers A/B
+    int strip = blockIdx.x, pair = blockIdx.z;
+    size_t fpitch = (size_t)W;
+    if constexpr (HET) {
+        const nsof_het_item& it = items[blockIdx.z];
+        W = it.wk;
+        H = it.hk;
+        if (blockIdx.x * SW >= W) return;   // block-uniform, before any barrier
+        R0b += it.offR;
+        R1b = R0b + 5 * (size_t)W * H;
+        pair_stride = 0;
+        pair = 0;
+        flow_in += 2 * it.offF;
+        if (het_final) {
+            flow_out = it.out;
+            fpitch = (size_t)it.out_pitch;
+        } else {
+            flow_out += 2 * it.offF;
+            fpitch = (size_t)W;
+        }
+    } else {
+#ifndef NSOF_NO_XCD_REMAP
+        const unsigned total = gridDim.x * gridDim.z;   // an XCD owns whole pairs (see k_iterate_pc)
+        if ((total & 7u) == 0) {
+            const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+            const unsigned j = (lin & 7u) * (total >> 3) + (lin >> 3);
+            pair = (int)(j / gridDim.x);
+            strip = (int)(j - (unsigned)pair * gridDim.x);
+        }
+#endif
+    }
+    const int x0 = strip * SW;
+    const int xc = clampi(x0 - MH + col, 0, W - 1);
+    const size_t plane = (size_t)W * H;
+    const Planes R0 = planes_of(R0b + (size_t)pair * pair_stride, plane);
+    const Planes R1 = planes_of(R1b + (size_t)pair * pair_stride, plane);
+    FlowSrc<false> F;
+    F.base = reinterpret_cast<const char*>(flow_in) + (size_t)pair * plane * 8;
+    F.W = (unsigned)W;
+    F.xc = (unsigned)xc;
+    float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)pair * plane;
+    const int nsteps = (H + 3) / 4;
+    if (role == 0)
+        q_consumer_loop<MH>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
+    else if (role == 1)
+        q_producer_loop<MH, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
+    else
+        q_producer_loop<MH, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
+}
+
+template <int MH>
+int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                     const float* flow_in, float* flow_out, int W, int H, int winsize)
+{
+    using G = QGeom<MH>;
+    if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false>, G::SMEM)) return rc;
+    dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
+    hipLaunchKernelGGL((k_iterate_q<MH, false>), grid, dim3(768), G::SMEM, ctx->stream, R0, R1, pair_stride, flow_in,
+                       flow_out, W, H, winsize, nullptr, 0);
+    return NSOF_OK;
+}
+
+template <int MH>
+int launch_iterate_q_het(nsof_ctx* ctx, int n_items, const nsof_het_item* items, int max_w, const float* R,
+                         const float* flow_in, float* flow_out, bool final, int winsize)
+{
+    using G = QGeom<MH>;
+    if (int rc = lds_opt_in(ctx, k_iterate_q<MH, true>, G::SMEM)) return rc;
+    dim3 grid((max_w + G::SW - 1) / G::SW, 1, n_items);
+    hipLaunchKernelGGL((k_iterate_q<MH, true>), grid, dim3(768), G::SMEM, ctx->stream, R, R, (size_t)0, flow_in, flow_out,
+                       0, 0, winsize, items, final ? 1 : 0);
+    return NSOF_OK;
+}
+
 template <int MH, int COLS, bool UPS>
 int launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                         const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
@@ -811,14 +1070,43 @@ bool nsof_iterate_supported(int winsize, int W, int H)
     return m >= 1 && m <= 8 && W >= 2 && H >= 2;   // the clamped gather needs a 2x2 neighbourhood to exist
 }
 
-static int g_iterate_variant = -1;   // NSOF_ITERATE=walker|pc (tuning / A-B runs); default pc
-static bool use_pc(int m)
+static int g_iterate_variant = -1;   // NSOF_ITERATE=walker|pc|quad (tuning / A-B runs); default quad
+static int iterate_variant()
 {
     if (g_iterate_variant < 0) {
         const char* e = getenv("NSOF_ITERATE");
-        g_iterate_variant = (e && e[0] == 'w') ? 0 : 1;
+        g_iterate_variant = (e && e[0] == 'w') ? 0 : (e && e[0] == 'p') ? 1 : 2;
     }
-    return g_iterate_variant == 1 && m <= 7;
+    return g_iterate_variant;
+}
+static bool use_pc(int m) { return iterate_variant() >= 1 && m <= 7; }
+static bool use_quad(int m) { return iterate_variant() == 2 && m <= 7; }
+
+template <typename... A>
+static int launch_iterate_q_m(int m, A... a)
+{
+    switch (m) {
+        case 1: return launch_iterate_q<1>(a...);
+        case 2: return launch_iterate_q<2>(a...);
+        case 3: return launch_iterate_q<3>(a...);
+        case 4: return launch_iterate_q<4>(a...);
+        case 5: return launch_iterate_q<5>(a...);
+        case 6: return launch_iterate_q<6>(a...);
+        default: return launch_iterate_q<7>(a...);
+    }
+}
+template <typename... A>
+static int launch_iterate_q_het_m(int m, A... a)
+{
+    switch (m) {
+        case 1: return launch_iterate_q_het<1>(a...);
+        case 2: return launch_iterate_q_het<2>(a...);
+        case 3: return launch_iterate_q_het<3>(a...);
+        case 4: return launch_iterate_q_het<4>(a...);
+        case 5: return launch_iterate_q_het<5>(a...);
+        case 6: return launch_iterate_q_het<6>(a...);
+        default: return launch_iterate_q_het<7>(a...);
+    }
 }
 
 // flow_in and flow_out must be different buffers (rows y+m of flow_in are read while row y of flow_out is written).
@@ -826,6 +1114,12 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
                         const float* flow_in, float* flow_out, int W, int H, int winsize)
 {
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    if (use_quad(winsize / 2)) {
+        if (int rc = launch_iterate_q_m(winsize / 2, ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize))
+            return rc;
+        NSOF_HIP(ctx, hipGetLastError());
+        return NSOF_OK;
+    }
     if (use_pc(winsize / 2)) {
         if (int rc = launch_iterate_pc_m<false>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H,
                                                 winsize, UpsArgs{}))
@@ -882,6 +1176,11 @@ int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
     if (m < 1 || m > 7) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "work-list iteration supports winsize 2..15");
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     int rc;
+    if (use_quad(m)) {
+        if ((rc = launch_iterate_q_het_m(m, ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize))) return rc;
+        NSOF_HIP(ctx, hipGetLastError());
+        return NSOF_OK;
+    }
     switch (m) {
         case 1: rc = launch_iterate_pc_het<1>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
         case 2: rc = launch_iterate_pc_het<2>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
