@@ -753,21 +753,21 @@ int lds_opt_in(nsof_ctx* ctx, K kernel, size_t bytes)
 // Arithmetic per pixel and its order are those of k_iterate_pc (pixels 4k+2, 4k+3 of a row reach their row sums by
 // sliding instead of by a direct sum: same double-precision values up to their last bit).
 // ---------------------------------------------------------------------------------------------
-template <int MH>
+template <int MH, int COLS_ = 256>
 struct QGeom {
-    static constexpr int COLS = 256, RB = 4;
+    static constexpr int COLS = COLS_, RB = 4;
     static constexpr int RL = 2 * MH + 1 + 2 * RB;
     static constexpr int SW = (COLS - 2 * MH) & ~3;         // a solve thread owns 4 whole pixels
     static constexpr size_t SV_BYTES = sizeof(double) * RB * 5 * COLS;
     static constexpr size_t SMEM = SV_BYTES + sizeof(float) * RL * 5 * COLS;
 };
 
-template <int MH, int GP, int TS, int RR>
-__device__ __forceinline__ void q_produce(RowIn (&in)[2][2], FlowSrc<false>::Raw (&fl)[2][2], float (*mring)[5][256],
+template <int MH, int COLS, int GP, int TS, int RR>
+__device__ __forceinline__ void q_produce(RowIn (&in)[2][2], FlowSrc<false>::Raw (&fl)[2][2], float (*mring)[5][COLS],
                                           const Planes& R0, const Planes& R1, const FlowSrc<false>& F, int W, int H, int xc,
                                           int col, int t)
 {
-    constexpr int RL = QGeom<MH>::RL;
+    constexpr int RL = QGeom<MH, COLS>::RL;
     const int i = 4 * t + MH + 2 * GP + RR;                  // stream index of this row
     float Mn[5];
     matrix_from(in[TS][RR], xc, min(i, H - 1), W, H, Mn);
@@ -778,8 +778,8 @@ __device__ __forceinline__ void q_produce(RowIn (&in)[2][2], FlowSrc<false>::Raw
     fl[TS][RR] = F.fetch(min(i + 16, H - 1));                                            // its flow for step t+4
 }
 
-template <int MH, int GP>
-__device__ __forceinline__ void q_producer_loop(float (*mring)[5][256], const Planes& R0, const Planes& R1,
+template <int MH, int COLS, int GP>
+__device__ __forceinline__ void q_producer_loop(float (*mring)[5][COLS], const Planes& R0, const Planes& R1,
                                                 const FlowSrc<false>& F, int W, int H, int xc, int col, int nsteps)
 {
     RowIn in[2][2];
@@ -800,30 +800,30 @@ __device__ __forceinline__ void q_producer_loop(float (*mring)[5][256], const Pl
     //   B_init .. B1(0)        first row of step 1            (consumers: column sums of step 0)
     //   B1(t) .. B2(t)         second row of step t+1         (consumers: row sums + solve of step t)
     //   B2(t) .. B1(t+1)       first row of step t+2          (consumers: column sums of step t+1)
-    q_produce<MH, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
-    q_produce<MH, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
+    q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
+    q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
     __syncthreads();
-    q_produce<MH, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
+    q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
     for (int tb = 0; tb < nsteps; tb += 2) {
         __syncthreads();                                                             // B1(tb)
-        q_produce<MH, GP, 1, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 1);
+        q_produce<MH, COLS, GP, 1, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 1);
         __syncthreads();                                                             // B2(tb)
-        q_produce<MH, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
+        q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
         if (tb + 1 >= nsteps) break;
         __syncthreads();                                                             // B1(tb+1)
-        q_produce<MH, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
+        q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
         __syncthreads();                                                             // B2(tb+1)
-        q_produce<MH, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 3);
+        q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 3);
     }
 }
 
-template <int MH>
-__device__ __forceinline__ void q_consumer_loop(float (*mring)[5][256], double (*sv)[5][256], const Planes& R0,
+template <int MH, int COLS>
+__device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
                                                 const Planes& R1, const FlowSrc<false>& F, float2* Fout, size_t fpitch,
                                                 int W, int H, int x0, int xc, int col, int nsteps, double scale)
 {
-    using G = QGeom<MH>;
-    constexpr int RL = G::RL, SW = G::SW;
+    using G = QGeom<MH, COLS>;
+    constexpr int RL = G::RL, SW = G::SW, TPR = COLS / 4;   // TPR solve threads per row
     double vs[5];
     {
         // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
@@ -852,7 +852,7 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][256], double (
         }
     }
     __syncthreads();   // B_init: step 0 is in the ring
-    const int hrow = col >> 6, t4 = col & 63;   // solve phase: 64 threads per row, 4 pixels each
+    const int hrow = col / TPR, t4 = col % TPR;   // solve phase: COLS/4 threads per row, 4 pixels each
     int slot_new = (2 * MH + 1) % RL;           // stream index m    -> slot 2m+1
     int slot_old = 0;                           // stream index -m-1 -> slot 0
     for (int t = 0; t < nsteps; t++) {
@@ -871,7 +871,7 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][256], double (
         __syncthreads();   // B1(t): column sums of step t visible
         const int yo = 4 * t + hrow, xo = x0 + 4 * t4;
         if (4 * t4 < SW && yo < H && xo < W) {
-            const double (*svr)[256] = sv[hrow];
+            const double (*svr)[COLS] = sv[hrow];
             double g[5];
             float2 o[4];
 #pragma unroll
@@ -908,19 +908,19 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][256], double (
     }
 }
 
-template <int MH, bool HET>
-__global__ __launch_bounds__(768) void k_iterate_q(const float* __restrict__ R0b, const float* __restrict__ R1b,
+template <int MH, bool HET, int COLS = 256>
+__global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict__ R0b, const float* __restrict__ R1b,
                                                     size_t pair_stride, const float* __restrict__ flow_in,
                                                     float* __restrict__ flow_out, int W, int H, int block_size,
                                                     const nsof_het_item* __restrict__ items, int het_final)
 {
-    using G = QGeom<MH>;
+    using G = QGeom<MH, COLS>;
     constexpr int SW = G::SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
-    double (*sv)[5][256] = reinterpret_cast<double (*)[5][256]>(smem_q);                       // [4 rows]
-    float (*mring)[5][256] = reinterpret_cast<float (*)[5][256]>(smem_q + G::SV_BYTES);        // [RL]
-    const int tid = threadIdx.x, col = tid & 255;
-    const int role = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform: 0 consumers, 1/2 producers A/B
+    double (*sv)[5][COLS] = reinterpret_cast<double (*)[5][COLS]>(smem_q);                      // [4 rows]
+    float (*mring)[5][COLS] = reinterpret_cast<float (*)[5][COLS]>(smem_q + G::SV_BYTES);       // [RL]
+    const int tid = threadIdx.x, col = tid % COLS;
+    const int role = __builtin_amdgcn_readfirstlane(tid / COLS);   // wave-uniform: 0 consumers, 1/2 producers A/B
     int strip = blockIdx.x, pair = blockIdx.z;
     size_t fpitch = (size_t)W;
     if constexpr (HET) {
@@ -963,17 +963,26 @@ __global__ __launch_bounds__(768) void k_iterate_q(const float* __restrict__ R0b
     float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)pair * plane;
     const int nsteps = (H + 3) / 4;
     if (role == 0)
-        q_consumer_loop<MH>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
+        q_consumer_loop<MH, COLS>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
     else if (role == 1)
-        q_producer_loop<MH, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
+        q_producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
     else
-        q_producer_loop<MH, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
+        q_producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
 }
 
 template <int MH>
 int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                      const float* flow_in, float* flow_out, int W, int H, int winsize)
 {
+    static const bool narrow = getenv("NSOF_Q_COLS128") != nullptr;   // A/B: two 128-column strips per CU
+    if (narrow) {
+        using G = QGeom<MH, 128>;
+        if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false, 128>, G::SMEM)) return rc;
+        dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
+        hipLaunchKernelGGL((k_iterate_q<MH, false, 128>), grid, dim3(384), G::SMEM, ctx->stream, R0, R1, pair_stride,
+                           flow_in, flow_out, W, H, winsize, nullptr, 0);
+        return NSOF_OK;
+    }
     using G = QGeom<MH>;
     if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false>, G::SMEM)) return rc;
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
