@@ -882,7 +882,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
             // per lane at a 64-B stride.  Transpose through LDS (per wave) so that every store instruction writes
             // 64 consecutive pixels = 1 KiB contiguous.
 #pragma unroll
-            for (int p = 0; p < 4; p++) st[wave][4 * lane + p] = make_float4(o0[p], o1[p], o2[p], o3[p]);
+            // (swizzled within each lane's 4 slots: unswizzled, the 8 lanes a ds_write_b128 serves per LDS cycle hit
+            //  only 2 of the 8 bank groups -- PMC: 63 % of this kernel's LDS cycles were bank conflicts)
+            for (int p = 0; p < 4; p++) st[wave][4 * lane + (p ^ ((lane >> 1) & 3))] = make_float4(o0[p], o1[p], o2[p], o3[p]);
         }
         {
             // every lane of the wave takes part (lanes beyond the strip read slots nobody wrote, and do not store)
@@ -891,7 +893,7 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int px = 64 * k + lane;   // pixel within the strip row
-                const float4 v = st[wave][px];
+                const float4 v = st[wave][(px & ~3) | ((px & 3) ^ ((px >> 3) & 3))];   // pixel px sits in lane px/4's slot
                 if (px < G::SW && yo2 < ye && x0 + px < W) nsof_store_stream4(reinterpret_cast<float*>(q4 + px), v.x, v.y, v.z, v.w);
             }
         }
