@@ -190,7 +190,7 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
 void parallel_rows(size_t n_tasks, const std::function<void(size_t)>& fn)
 {
     static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, hw), n_tasks);
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(16u, std::max(1u, hw / 2)), n_tasks);
     if (nt <= 1) {
         for (size_t i = 0; i < n_tasks; i++) fn(i);
         return;
@@ -213,7 +213,8 @@ struct nsof_pipe {
         void* h_in = nullptr;  size_t h_in_bytes = 0;
         void* h_out = nullptr; size_t h_out_bytes = 0;
         hipEvent_t in_done = nullptr, compute_done = nullptr, out_done = nullptr;
-    } slot[2];
+    } slot[3];
+    static constexpr int NSLOT = 3;
 };
 
 void nsof_pipe_destroy(nsof_ctx* ctx)
@@ -319,9 +320,11 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
     nsof_pipe* pp;
     if (int rc = pipe_get(ctx, &pp)) return rc;
 
-    // chunks of the list: about 1 GiB of flow (64 pairs of 1920x1080) each, so that the stages have work to overlap
+    // chunks of the list: about 256 MiB of flow (16 pairs of 1920x1080) each -- small enough that upload, compute
+    // and download of neighbouring chunks overlap for lists of a few dozen frames, large enough that the work list
+    // of a chunk still fills the GPU (the download, not the compute, bounds the pipeline: 16.6 MB per 1080p pair)
     const char* chunk_env = getenv("NSOF_PIPE_CHUNK_MB");   // tests shrink it to force several chunks
-    const size_t budget = (size_t)std::max(1l, chunk_env ? atol(chunk_env) : 1024l) << 20;
+    const size_t budget = (size_t)std::max(1l, chunk_env ? atol(chunk_env) : 256l) << 20;
     std::vector<Chunk> chunks;
     for (int i = 0; i < n_pairs;) {
         Chunk c;
@@ -361,33 +364,56 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
     };
 
     const int nc = (int)chunks.size();
+    constexpr int NS = nsof_pipe::NSLOT;
     std::vector<nsof_pair_desc> dd;
+    std::vector<char> finished(nc, 0);
     for (int ci = 0; ci < nc; ci++) {
         const Chunk& c = chunks[ci];
-        nsof_pipe::Slot& s = pp->slot[ci & 1];
-        if (ci >= 2) {   // the slot's previous chunk must have left it
-            if (int rc = finish(chunks[ci - 2], s)) return rc;
+        nsof_pipe::Slot& s = pp->slot[ci % NS];
+        const bool reuse = ci >= NS;           // the slot carried chunk ci - NS
+        bool chunk_pageable_out = false;
+        for (int i = c.lo; i < c.hi; i++) chunk_pageable_out = chunk_pageable_out || !pin_out[i];
+        // Host-side waits only where host memory is reused: the slot's pinned input staging (its upload has long
+        // finished) and, for pageable outputs, its pinned output staging (must be unpacked before the next download
+        // lands in it).  Everything else is ordered on the GPU by events, so the host runs ahead and packs.
+        if (reuse) {
+            NSOF_HIP(ctx, hipEventSynchronize(s.in_done));
+            if (!finished[ci - NS]) {
+                bool prev_pageable = false;
+                for (int i = chunks[ci - NS].lo; i < chunks[ci - NS].hi; i++) prev_pageable = prev_pageable || !pin_out[i];
+                if (prev_pageable || s.h_out_bytes < c.out_bytes || s.d_out_bytes < c.out_bytes || s.d_in_bytes < c.in_bytes ||
+                    s.h_in_bytes < c.in_bytes) {
+                    if (int rc = finish(chunks[ci - NS], s)) return rc;
+                    finished[ci - NS] = 1;
+                }
+            }
         }
         int rc;
         if ((rc = grow_dev(ctx, &s.d_in, &s.d_in_bytes, c.in_bytes)) || (rc = grow_dev(ctx, &s.d_out, &s.d_out_bytes, c.out_bytes)) ||
-            (rc = grow_host(ctx, &s.h_in, &s.h_in_bytes, c.in_bytes)) || (rc = grow_host(ctx, &s.h_out, &s.h_out_bytes, c.out_bytes)))
+            (rc = grow_host(ctx, &s.h_in, &s.h_in_bytes, c.in_bytes)) ||
+            (chunk_pageable_out && (rc = grow_host(ctx, &s.h_out, &s.h_out_bytes, c.out_bytes))))
             return rc;
         // stage 1: frames -> device (pageable / strided sources are packed into the pinned slot buffer by a few threads)
         std::vector<std::array<int, 3>> rows;   // (item, frame, first row)
         for (int i = c.lo; i < c.hi; i++)
             for (int f = 0; f < 2; f++)
                 if (!pin_in[2 * i + f])
-                    for (int y = 0; y < pairs[i].height; y += 256) rows.push_back({i, f, y});
+                    for (int y = 0; y < pairs[i].height; y += 128) rows.push_back({i, f, y});
         parallel_rows(rows.size(), [&](size_t t) {
             const int i = rows[t][0], f = rows[t][1], y0 = rows[t][2];
             const nsof_pair_desc& d = pairs[i];
             const uint8_t* src = f ? d.next : d.prev;
             const ptrdiff_t st = f ? d.next_stride : d.prev_stride;
             uint8_t* dst = (uint8_t*)s.h_in + c.in_off[f][i - c.lo];
-            for (int y = y0; y < std::min(y0 + 256, d.height); y++)
-                memcpy(dst + (size_t)y * d.width, src + (ptrdiff_t)y * st, (size_t)d.width);
+            const int y1 = std::min(y0 + 128, d.height);
+            if (st == (ptrdiff_t)d.width) {
+                memcpy(dst + (size_t)y0 * d.width, src + (ptrdiff_t)y0 * st, (size_t)(y1 - y0) * d.width);
+            } else {
+                for (int y = y0; y < y1; y++) memcpy(dst + (size_t)y * d.width, src + (ptrdiff_t)y * st, (size_t)d.width);
+            }
         });
-        bool any_packed = !rows.empty(), all_packed = true;
+        if (reuse) NSOF_HIP(ctx, hipStreamWaitEvent(pp->s_in, s.compute_done, 0));   // d_in was read by chunk ci - NS
+        bool all_packed = true;
         for (int i = c.lo; i < c.hi; i++) all_packed = all_packed && !pin_in[2 * i] && !pin_in[2 * i + 1];
         if (all_packed) {
             NSOF_HIP(ctx, hipMemcpyAsync(s.d_in, s.h_in, c.in_bytes, hipMemcpyHostToDevice, pp->s_in));
@@ -400,10 +426,10 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
                     NSOF_HIP(ctx, hipMemcpyAsync((char*)s.d_in + off, src, n0, hipMemcpyHostToDevice, pp->s_in));
                 }
         }
-        (void)any_packed;
         NSOF_HIP(ctx, hipEventRecord(s.in_done, pp->s_in));
         // stage 2: compute on the context's stream
         NSOF_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.in_done, 0));
+        if (reuse) NSOF_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.out_done, 0));   // d_out is being downloaded (chunk ci - NS)
         dd.resize(c.hi - c.lo);
         for (int i = c.lo; i < c.hi; i++) {
             nsof_pair_desc& d = dd[i - c.lo];
@@ -419,23 +445,29 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
         NSOF_HIP(ctx, hipEventRecord(s.compute_done, ctx->stream));
         // stage 3: flow -> host
         NSOF_HIP(ctx, hipStreamWaitEvent(pp->s_out, s.compute_done, 0));
-        bool none_pinned = true;
-        for (int i = c.lo; i < c.hi; i++) none_pinned = none_pinned && !pin_out[i];
-        if (none_pinned) {
-            NSOF_HIP(ctx, hipMemcpyAsync(s.h_out, s.d_out, c.out_bytes, hipMemcpyDeviceToHost, pp->s_out));
-        } else {
+        if (!chunk_pageable_out) {
             for (int i = c.lo; i < c.hi; i++) {
                 const size_t off = c.out_off[i - c.lo], nb = (size_t)pairs[i].width * pairs[i].height * 8;
-                void* dst = pin_out[i] ? (void*)pairs[i].flow : (void*)((char*)s.h_out + off);
-                NSOF_HIP(ctx, hipMemcpyAsync(dst, (char*)s.d_out + off, nb, hipMemcpyDeviceToHost, pp->s_out));
+                NSOF_HIP(ctx, hipMemcpyAsync(pairs[i].flow, (char*)s.d_out + off, nb, hipMemcpyDeviceToHost, pp->s_out));
+            }
+        } else {
+            bool none_pinned = true;
+            for (int i = c.lo; i < c.hi; i++) none_pinned = none_pinned && !pin_out[i];
+            if (none_pinned) {
+                NSOF_HIP(ctx, hipMemcpyAsync(s.h_out, s.d_out, c.out_bytes, hipMemcpyDeviceToHost, pp->s_out));
+            } else {
+                for (int i = c.lo; i < c.hi; i++) {
+                    const size_t off = c.out_off[i - c.lo], nb = (size_t)pairs[i].width * pairs[i].height * 8;
+                    void* dst = pin_out[i] ? (void*)pairs[i].flow : (void*)((char*)s.h_out + off);
+                    NSOF_HIP(ctx, hipMemcpyAsync(dst, (char*)s.d_out + off, nb, hipMemcpyDeviceToHost, pp->s_out));
+                }
             }
         }
         NSOF_HIP(ctx, hipEventRecord(s.out_done, pp->s_out));
-        // the next chunk's upload may not overwrite this slot's partner before ITS compute has consumed it: the
-        // partner slot is only reused two chunks later, after finish() has waited for its download
     }
-    for (int ci = std::max(0, nc - 2); ci < nc; ci++)
-        if (int rc = finish(chunks[ci], pp->slot[ci & 1])) return rc;
+    for (int ci = 0; ci < nc; ci++)
+        if (!finished[ci])
+            if (int rc = finish(chunks[ci], pp->slot[ci % NS])) return rc;
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NSOF_OK;
 }
