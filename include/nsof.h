@@ -203,6 +203,23 @@ int nsof_accum_reset(nsof_accum* acc);
 int nsof_accum_step_events(nsof_accum* acc, const int16_t* x, const int16_t* y, const int8_t* p,
                            const int64_t* t, const int64_t* slice_bounds, int64_t n_slices,
                            int64_t snap_every);
+/* The same in two halves, for streams that are advanced piecewise or re-run: nsof_accum_set_events uploads the
+ * events of slices [0, n_slices) ONCE (arrays and bounds as above; nothing is retained but the device copy), and
+ * nsof_accum_run advances over any sub-range [first_slice, first_slice + n_slices) of them without touching the
+ * host arrays again.  nsof_accum_step_events == set_events followed by run(0, n_slices). */
+int nsof_accum_set_events(nsof_accum* acc, const int16_t* x, const int16_t* y, const int8_t* p,
+                          const int64_t* t, const int64_t* slice_bounds, int64_t n_slices);
+int nsof_accum_run(nsof_accum* acc, int64_t first_slice, int64_t n_slices, int64_t snap_every);
+/* The current surface as an 8-bit frame on the DEVICE: g = uint8(clip(-3366/log10(I) - 306, 0, 255)), I = 1/R,
+ * R = resistance_exp(w) -- the reference's map from device current to the gating image (optical_flow_seg.py:
+ * 426-431) applied per pixel.  d_out uint8 [H][row_stride].  Asynchronous on the context's stream. */
+int nsof_accum_surface_u8_dev(nsof_accum* acc, int which, uint8_t* d_out, ptrdiff_t row_stride);
+/* Checkpoint / resume (the reference persists only w_final, event_mem_sim.py:289-303): copy one array's state to /
+ * from HOST memory -- w float32 [H][W], the refractory map int64 [H][W] (scheme 2; zeros otherwise) and the global
+ * slice counter that times the snapshots.  NULL pointers are skipped. */
+int nsof_accum_read_state(nsof_accum* acc, int which, float* w_out, int64_t* next_ok_out, int64_t* slice_counter);
+int nsof_accum_write_state(nsof_accum* acc, int which, const float* w_in, const int64_t* next_ok_in,
+                           int64_t slice_counter);
 /* Dense element-wise update_state on DEVICE arrays (event_mem_sim.py:40-57). */
 int nsof_accum_update_state_dev(nsof_ctx* ctx, const float* d_w, const float* d_V, float* d_out, size_t n);
 /* bincount_2d(x, y, H, W) of event_mem_sim.py:100-104: events per pixel, int32 [H][W].  HOST arrays in and out;

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "nsof_internal.h"
 
@@ -282,6 +283,20 @@ __global__ __launch_bounds__(64) void k_frame_step(const double* __restrict__ a,
     res[i] = RON / exp(-lambda * (1 - ww));
 }
 
+// Temporal-prior surface as an 8-bit frame: the reference's bridge from device state to the gating input,
+// g = uint8(clip(-3366 / log10(I) - 306, 0, 255)) with I = V_ds / R, V_ds = 1 V (optical_flow_seg.py:426-431,
+// simulationcode_v4_transistor_uav.m:36), evaluated per pixel in double on R = resistance_exp(w) as float32.
+__global__ __launch_bounds__(256) void k_surface_gray(const float* __restrict__ w, uint8_t* __restrict__ out, int W, int H,
+                                                       ptrdiff_t stride, float neg_lam)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const double r = (double)resistance_one(w[(size_t)y * W + x], neg_lam);
+    double g = -3366.0 / log10(1.0 / r) - 306.0;
+    g = g < 0.0 ? 0.0 : (g > 255.0 ? 255.0 : g);   // NaN (I == 1 A exactly) cannot occur for R in [Ron, Roff]
+    out[(ptrdiff_t)y * stride + x] = (uint8_t)g;
+}
+
 // bincount_2d (event_mem_sim.py:100-104): events per pixel.
 __global__ __launch_bounds__(256) void k_bincount(const short* __restrict__ x, const short* __restrict__ y, size_t n,
                                                    int W, int* __restrict__ counts)
@@ -319,6 +334,9 @@ struct nsof_accum {
     float* snap[2] = {nullptr, nullptr};
     int64_t snap_cap = 0, snap_count = 0;
     int64_t slice_counter = 0;
+    // staged stream (nsof_accum_set_events / the staging half of nsof_accum_step_events): slice bounds relative to
+    // the first staged event, and for scheme 2 the first / last+refractory timestamp of every slice
+    std::vector<long long> h_rel, h_tfirst, h_tnext;
 };
 
 static int accum_alloc(nsof_ctx* ctx, void** p, size_t bytes)
@@ -423,13 +441,14 @@ static int accum_snapshot(nsof_accum* a)
     return NSOF_OK;
 }
 
-extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int16_t* y, const int8_t* p,
-                                      const int64_t* t, const int64_t* sb, int64_t n_slices, int64_t snap_every)
+// Upload the events of slices [0, n_slices) (bounds sb index the caller's arrays) and keep what the slice loop needs
+// on the host: the bounds relative to the first uploaded event and, for scheme 2, every slice's first timestamp and
+// last timestamp + refractory period.
+static int accum_stage(nsof_accum* a, const int16_t* x, const int16_t* y, const int8_t* p, const int64_t* t,
+                       const int64_t* sb, int64_t n_slices)
 {
-    if (!a) return NSOF_EINVAL;
     nsof_ctx* ctx = a->ctx;
     if (n_slices < 0 || !sb) return nsof_set_error(ctx, NSOF_EINVAL, "bad slice bounds");
-    if (n_slices == 0) return NSOF_OK;
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t e0 = sb[0], e1 = sb[n_slices], n_ev = e1 - e0;
     if (n_ev < 0) return nsof_set_error(ctx, NSOF_EINVAL, "slice bounds not monotone");
@@ -444,7 +463,6 @@ extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int
                                   (int)x[e], (int)y[e], a->W, a->H);
     const int narr = a->split ? 2 : 1;
     int rc;
-    // stage events + bounds (relative to e0)
     if ((size_t)n_ev > a->ev_cap) {
         NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
         hipFree(a->dx); hipFree(a->dy); hipFree(a->dp);
@@ -469,19 +487,41 @@ extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int
         NSOF_HIP(ctx, hipMemcpyAsync(a->dy, y + e0, (size_t)n_ev * 2, hipMemcpyHostToDevice, ctx->stream));
         if (p) NSOF_HIP(ctx, hipMemcpyAsync(a->dp, p + e0, (size_t)n_ev, hipMemcpyHostToDevice, ctx->stream));
     }
-    std::vector<long long> rel((size_t)n_slices + 1);
-    for (int64_t s = 0; s <= n_slices; s++) rel[s] = (long long)(sb[s] - e0);
-    NSOF_HIP(ctx, hipMemcpyAsync(a->dbounds, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rel is a stack-lifetime buffer
+    a->h_rel.resize((size_t)n_slices + 1);
+    for (int64_t s = 0; s <= n_slices; s++) a->h_rel[s] = (long long)(sb[s] - e0);
+    a->h_tfirst.assign((size_t)n_slices, 0);
+    a->h_tnext.assign((size_t)n_slices, 0);
+    if (a->scheme == 2)
+        for (int64_t s = 0; s < n_slices; s++)
+            if (sb[s + 1] > sb[s]) {
+                a->h_tfirst[s] = t[sb[s]];
+                a->h_tnext[s] = t[sb[s + 1] - 1] + REFRACTORY_US;
+            }
+    NSOF_HIP(ctx, hipMemcpyAsync(a->dbounds, a->h_rel.data(), a->h_rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays are not retained
+    return NSOF_OK;
+}
 
+// Advance over staged slices [s_begin, s_begin + n_slices).
+static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64_t snap_every)
+{
+    nsof_ctx* ctx = a->ctx;
+    if (s_begin < 0 || n_slices < 0 || (size_t)(s_begin + n_slices + 1) > a->h_rel.size())
+        return nsof_set_error(ctx, NSOF_EINVAL, "slices [%lld, %lld) outside the staged stream", (long long)s_begin,
+                              (long long)(s_begin + n_slices));
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const int narr = a->split ? 2 : 1;
+    int rc;
+    const std::vector<long long>& rel = a->h_rel;
     const bool dead_zone = !(a->silent_v < VOFF) && !(a->silent_v > VON);
     const bool sparse = dead_zone && !a->force_dense;
     const float v_act = a->scheme == 1 ? a->active_v : a->silent_v + a->active_v;
 
-    int64_t s0 = 0;
-    while (s0 < n_slices) {
+    int64_t s0 = s_begin;
+    const int64_t s_end = s_begin + n_slices;
+    while (s0 < s_end) {
         // group = up to 32 slices, ending right after the next snapshot slice
-        int64_t g = n_slices - s0 < MAX_GROUP ? n_slices - s0 : MAX_GROUP;
+        int64_t g = s_end - s0 < MAX_GROUP ? s_end - s0 : MAX_GROUP;
         if (snap_every > 0) {
             const int64_t c = a->slice_counter;
             const int64_t to_snap = (c % snap_every == 0) ? 1 : (snap_every - c % snap_every) + 1;
@@ -498,7 +538,7 @@ extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int
                 for (int64_t s = 0; s < g; s++) {
                     const long long lo = rel[s0 + s], hi = rel[s0 + s + 1];
                     if (hi <= lo) continue;
-                    const long long t_first = t[e0 + lo], t_next = t[e0 + hi - 1] + REFRACTORY_US;
+                    const long long t_first = a->h_tfirst[s0 + s], t_next = a->h_tnext[s0 + s];
                     const unsigned bit = 1u << s;
                     const dim3 grid((unsigned)((hi - lo + 255) / 256));
                     if (a->split) {
@@ -541,6 +581,74 @@ extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int
         if (snap_every > 0 && (a->slice_counter - 1) % snap_every == 0)
             if ((rc = accum_snapshot(a))) return rc;
     }
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int16_t* y, const int8_t* p,
+                                      const int64_t* t, const int64_t* sb, int64_t n_slices, int64_t snap_every)
+{
+    if (!a) return NSOF_EINVAL;
+    if (n_slices == 0) return NSOF_OK;
+    if (int rc = accum_stage(a, x, y, p, t, sb, n_slices)) return rc;
+    return accum_advance(a, 0, n_slices, snap_every);
+}
+
+extern "C" int nsof_accum_set_events(nsof_accum* a, const int16_t* x, const int16_t* y, const int8_t* p,
+                                     const int64_t* t, const int64_t* sb, int64_t n_slices)
+{
+    if (!a) return NSOF_EINVAL;
+    return accum_stage(a, x, y, p, t, sb, n_slices);
+}
+
+extern "C" int nsof_accum_run(nsof_accum* a, int64_t first_slice, int64_t n_slices, int64_t snap_every)
+{
+    if (!a) return NSOF_EINVAL;
+    return accum_advance(a, first_slice, n_slices, snap_every);
+}
+
+extern "C" int nsof_accum_surface_u8_dev(nsof_accum* a, int which, uint8_t* d_out, ptrdiff_t row_stride)
+{
+    if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const float neg_lam = (float)(-std::log(ROFF / RON));
+    dim3 grid((a->W + 255) / 256, a->H);
+    hipLaunchKernelGGL(k_surface_gray, grid, dim3(256), 0, ctx->stream, a->w[which], d_out, a->W, a->H, row_stride, neg_lam);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// Checkpoint / resume: the whole state of one array is w (float32 [H][W]), its refractory map (int64 [H][W],
+// scheme 2) and the global slice counter that times the snapshots.
+extern "C" int nsof_accum_read_state(nsof_accum* a, int which, float* w_out, int64_t* next_ok_out, int64_t* slice_counter)
+{
+    if (!a || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    if (w_out) NSOF_HIP(ctx, hipMemcpyAsync(w_out, a->w[which], a->npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (next_ok_out) {
+        if (a->next_ok[which])
+            NSOF_HIP(ctx, hipMemcpyAsync(next_ok_out, a->next_ok[which], a->npx * 8, hipMemcpyDeviceToHost, ctx->stream));
+        else
+            memset(next_ok_out, 0, a->npx * 8);
+    }
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (slice_counter) *slice_counter = a->slice_counter;
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_write_state(nsof_accum* a, int which, const float* w_in, const int64_t* next_ok_in,
+                                      int64_t slice_counter)
+{
+    if (!a || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    if (slice_counter < 0) return nsof_set_error(ctx, NSOF_EINVAL, "negative slice counter");
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    if (w_in) NSOF_HIP(ctx, hipMemcpyAsync(a->w[which], w_in, a->npx * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (next_ok_in && a->next_ok[which])
+        NSOF_HIP(ctx, hipMemcpyAsync(a->next_ok[which], next_ok_in, a->npx * 8, hipMemcpyHostToDevice, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    a->slice_counter = slice_counter;
     return NSOF_OK;
 }
 

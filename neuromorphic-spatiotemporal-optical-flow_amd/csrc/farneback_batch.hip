@@ -13,6 +13,7 @@
 //     (upload of chunk c+1 and download of chunk c-1 on their own streams while chunk c computes).
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -365,6 +366,17 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
 
     const int nc = (int)chunks.size();
     constexpr int NS = nsof_pipe::NSLOT;
+    // NSOF_PIPE_TRACE=1: device-side begin/end of every stage of every chunk (timing events), printed at the end
+    const bool trace = getenv("NSOF_PIPE_TRACE") != nullptr;
+    std::vector<std::array<hipEvent_t, 6>> tev(trace ? nc : 0);
+    std::vector<std::array<double, 2>> thost(trace ? nc : 0);
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_call = now_ms();
+    auto mark = [&](int ci, int k, hipStream_t st) {
+        if (!trace) return;
+        hipEventCreate(&tev[ci][k]);
+        hipEventRecord(tev[ci][k], st);
+    };
     std::vector<nsof_pair_desc> dd;
     std::vector<char> finished(nc, 0);
     for (int ci = 0; ci < nc; ci++) {
@@ -394,6 +406,7 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
             (chunk_pageable_out && (rc = grow_host(ctx, &s.h_out, &s.h_out_bytes, c.out_bytes))))
             return rc;
         // stage 1: frames -> device (pageable / strided sources are packed into the pinned slot buffer by a few threads)
+        if (trace) thost[ci][0] = now_ms() - t_call;
         std::vector<std::array<int, 3>> rows;   // (item, frame, first row)
         for (int i = c.lo; i < c.hi; i++)
             for (int f = 0; f < 2; f++)
@@ -412,7 +425,9 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
                 for (int y = y0; y < y1; y++) memcpy(dst + (size_t)y * d.width, src + (ptrdiff_t)y * st, (size_t)d.width);
             }
         });
+        if (trace) thost[ci][1] = now_ms() - t_call;
         if (reuse) NSOF_HIP(ctx, hipStreamWaitEvent(pp->s_in, s.compute_done, 0));   // d_in was read by chunk ci - NS
+        mark(ci, 0, pp->s_in);
         bool all_packed = true;
         for (int i = c.lo; i < c.hi; i++) all_packed = all_packed && !pin_in[2 * i] && !pin_in[2 * i + 1];
         if (all_packed) {
@@ -427,6 +442,7 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
                 }
         }
         NSOF_HIP(ctx, hipEventRecord(s.in_done, pp->s_in));
+        mark(ci, 1, pp->s_in);
         // stage 2: compute on the context's stream
         NSOF_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.in_done, 0));
         if (reuse) NSOF_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.out_done, 0));   // d_out is being downloaded (chunk ci - NS)
@@ -441,10 +457,13 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
             d.flow = (float*)((char*)s.d_out + c.out_off[i - c.lo]);
             d.flow_stride = (ptrdiff_t)pairs[i].width * 8;
         }
+        mark(ci, 2, ctx->stream);
         if ((rc = het_core(ctx, c.hi - c.lo, dd.data(), p))) return rc;
         NSOF_HIP(ctx, hipEventRecord(s.compute_done, ctx->stream));
+        mark(ci, 3, ctx->stream);
         // stage 3: flow -> host
         NSOF_HIP(ctx, hipStreamWaitEvent(pp->s_out, s.compute_done, 0));
+        mark(ci, 4, pp->s_out);
         if (!chunk_pageable_out) {
             for (int i = c.lo; i < c.hi; i++) {
                 const size_t off = c.out_off[i - c.lo], nb = (size_t)pairs[i].width * pairs[i].height * 8;
@@ -464,11 +483,24 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
             }
         }
         NSOF_HIP(ctx, hipEventRecord(s.out_done, pp->s_out));
+        mark(ci, 5, pp->s_out);
     }
     for (int ci = 0; ci < nc; ci++)
         if (!finished[ci])
             if (int rc = finish(chunks[ci], pp->slot[ci % NS])) return rc;
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (trace) {
+        fprintf(stderr, "[nsof pipe] %d chunks, host total %.2f ms; per chunk: pairs | host pack begin..end | h2d | compute | d2h (ms from first upload)\n",
+                nc, now_ms() - t_call);
+        for (int ci = 0; ci < nc; ci++) {
+            float t[6];
+            for (int k = 0; k < 6; k++) hipEventElapsedTime(&t[k], tev[0][0], tev[ci][k]);
+            fprintf(stderr, "[nsof pipe] %3d: %4d | %7.2f..%7.2f | %7.2f..%7.2f | %7.2f..%7.2f | %7.2f..%7.2f\n", ci,
+                    chunks[ci].hi - chunks[ci].lo, thost[ci][0], thost[ci][1], t[0], t[1], t[2], t[3], t[4], t[5]);
+        }
+        for (auto& a : tev)
+            for (auto e : a) hipEventDestroy(e);
+    }
     return NSOF_OK;
 }
 

@@ -169,6 +169,50 @@ class Accumulator:
                                                             t.ctypes.data, bounds.ctypes.data, bounds.size - 1,
                                                             int(snap_every)), "accum_step_events")
 
+    def set_events(self, x, y, p, t, bounds):
+        """Upload the events of all slices once (``nsof_accum_set_events``); ``run`` then advances over sub-ranges."""
+        x = np.ascontiguousarray(x, np.int16)
+        y = np.ascontiguousarray(y, np.int16)
+        p = np.ascontiguousarray(p, np.int8)
+        t = np.ascontiguousarray(t, np.int64)
+        bounds = np.ascontiguousarray(bounds, np.int64)
+        if bounds.size < 1 or bounds[-1] > x.size or not (x.size == y.size == p.size == t.size):
+            raise NsofValueError("event arrays shorter than the slice bounds")
+        self.n_staged = bounds.size - 1
+        self.ctx.check(self.ctx._lib.nsof_accum_set_events(self._p, x.ctypes.data, y.ctypes.data, p.ctypes.data,
+                                                           t.ctypes.data, bounds.ctypes.data, bounds.size - 1),
+                       "accum_set_events")
+
+    def run(self, first_slice, n_slices, snap_every=0):
+        self.ctx.check(self.ctx._lib.nsof_accum_run(self._p, int(first_slice), int(n_slices), int(snap_every)),
+                       "accum_run")
+
+    def surface_u8(self, d_out, which=0, row_stride=None):
+        """The current surface as an 8-bit frame written to DEVICE memory (torch uint8 tensor / address)."""
+        self.ctx.check(self.ctx._lib.nsof_accum_surface_u8_dev(self._p, which, dev_ptr(d_out),
+                                                               self.W if row_stride is None else int(row_stride)),
+                       "accum_surface_u8")
+
+    def state(self, which=0):
+        """-> dict(w float32 [H][W], next_ok int64 [H][W], slice_counter) -- everything a resume needs."""
+        w = np.empty((self.H, self.W), np.float32)
+        nok = np.empty((self.H, self.W), np.int64)
+        cnt = C.c_int64()
+        self.ctx.check(self.ctx._lib.nsof_accum_read_state(self._p, which, w.ctypes.data, nok.ctypes.data,
+                                                           C.byref(cnt)), "accum_read_state")
+        return dict(w=w, next_ok=nok, slice_counter=cnt.value)
+
+    def load_state(self, state, which=0):
+        """Inverse of ``state()`` (e.g. ``w_final`` of a stored run: ``load_state(dict(w=w_final, slice_counter=n))``)."""
+        w = np.ascontiguousarray(state["w"], np.float32)
+        if w.shape != (self.H, self.W):
+            raise NsofValueError(f"state is {w.shape}, the array is {(self.H, self.W)}")
+        nok = state.get("next_ok")
+        nok = None if nok is None else np.ascontiguousarray(nok, np.int64)
+        self.ctx.check(self.ctx._lib.nsof_accum_write_state(self._p, which, w.ctypes.data,
+                                                            None if nok is None else nok.ctypes.data,
+                                                            int(state.get("slice_counter", 0))), "accum_write_state")
+
     def w(self, which=0):
         out = np.empty((self.H, self.W), np.float32)
         self.ctx.check(self.ctx._lib.nsof_accum_read_w(self._p, which, out.ctypes.data), "accum_read_w")

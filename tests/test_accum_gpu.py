@@ -224,3 +224,146 @@ def test_full_size_sensor_properties(nsof_lib, ctx, oracle):
         V[y[idx[s]:idx[s + 1]], x[idx[s]:idx[s + 1]]] = -6.0
         w = oracle.accum_update_state(w, V)
     assert np.abs(one - w).max() <= W_ATOL
+
+
+@pytest.mark.parametrize("version,polarity", [(1, "split"), (2, "split"), (2, "magnitude")])
+def test_staged_events_and_resume(nsof_lib, ctx, version, polarity):
+    """nsof_accum_set_events + nsof_accum_run over sub-ranges == one nsof_accum_step_events call, and a run that is
+    checkpointed (w, refractory map, slice counter), torn down and resumed in a NEW accumulator ends in the same state
+    with the same snapshots (the reference persists only w_final, event_mem_sim.py:289-303)."""
+    from nsof import synth
+    W, H = 96, 64
+    x, y, p, t = synth.make_events(5, W, H, 20000, 300_000, box=(20, 12))
+    idx = nsof_lib.accumulator.slice_index_array(t, 1000)
+    n = len(idx) - 1
+    one = nsof_lib.Accumulator(H, W, version, polarity, -6.0, 0.0, ctx=ctx)
+    one.step(x, y, p, t, idx, snap_every=7)
+    want_w = [one.w(k) for k in range(2 if one.split else 1)]
+    want_snaps = one.snapshots()
+    one.close()
+
+    a = nsof_lib.Accumulator(H, W, version, polarity, -6.0, 0.0, ctx=ctx)
+    a.set_events(x, y, p, t, idx)
+    cut = n // 3 + 5
+    a.run(0, cut, snap_every=7)
+    states = [a.state(k) for k in range(2 if a.split else 1)]
+    first_snaps = a.snapshots()
+    a.close()
+    assert states[0]["slice_counter"] == cut
+    b = nsof_lib.Accumulator(H, W, version, polarity, -6.0, 0.0, ctx=ctx)
+    for k, st in enumerate(states):
+        b.load_state(st, k)
+    b.set_events(x, y, p, t, idx)
+    b.run(cut, n - cut, snap_every=7)
+    for k in range(len(want_w)):
+        assert np.array_equal(b.w(k), want_w[k])
+    second = b.snapshots()
+    for k in range(len(want_w)):
+        assert np.array_equal(np.concatenate([first_snaps[k], second[k]], 0), want_snaps[k])
+    b.close()
+
+
+def test_surface_u8_matches_host_map(nsof_lib, ctx, torch_dev):
+    """nsof_accum_surface_u8_dev == the reference's current -> gray map (optical_flow_seg.py:426-431) applied on the host
+    to the resistances the accumulator reports: identical but for the last-ulp of log10 at integer boundaries."""
+    import torch
+    from nsof import gating, synth
+    W, H = 160, 120
+    x, y, p, t = synth.make_events(9, W, H, 30000, 200_000, box=(30, 20))
+    idx = nsof_lib.accumulator.slice_index_array(t, 1000)
+    acc = nsof_lib.Accumulator(H, W, 1, "split", -8.0, 0.0, ctx=ctx)
+    acc.step(x, y, p, t, idx)
+    out = torch.zeros((H, W + 16), dtype=torch.uint8, device=torch_dev)
+    torch.cuda.synchronize()
+    acc.surface_u8(out, row_stride=W + 16)
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    want = gating.current_to_gray(1.0 / acc.resistance().astype(np.float64))
+    acc.close()
+    assert not got[:, W:].any()
+    d = np.abs(got[:, :W].astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-4
+    assert want.max() > want.min()        # the box left a visible trace
+
+
+def test_row_bands_with_real_accumulator(nsof_lib, ctx):
+    """nsof.dist.simulate_banded with the GPU accumulator as the band callback on an RCCL process group (world size
+    1 on this box): bands on the global slice grid, empty-band contract, gather on the device."""
+    import torch.distributed as dist
+    from nsof import dist as nd
+    from nsof import synth
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29950 + os.getpid() % 40)
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("LOCAL_RANK", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl")
+    try:
+        W, H = 64, 47
+        x, y, p, t = synth.make_events(11, W, H, 3000, 40_000, box=(12, 9))
+
+        def band(xb, yb, pb, tb, idx_b, hw):
+            if hw[0] == 0:
+                return np.zeros(hw, np.float32)
+            acc = nsof_lib.Accumulator(hw[0], hw[1], 1, "split", -6.0, 0.0, ctx=ctx)
+            try:
+                acc.step(xb, yb, pb, tb, idx_b)
+                return acc.w()
+            finally:
+                acc.close()
+
+        out = nd.simulate_banded(x, y, p, t, (H, W), 1000, band)
+        full = nsof_lib.simulate((x, y, p, t), version=1, slice_us=1000, active_v=-6.0, silent_v=0.0,
+                                 sensor_size=(H, W), ctx=ctx)["w_final"]
+        assert np.array_equal(out.numpy(), full)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_hdf5_event_file_round_trip(nsof_lib, tmp_path):
+    """load_events + simulate(h5_path) on a /CD/events file (event_mem_sim.py:69-75, 359-364) and the file set the
+    reference writes next to it (:289-322).  h5py lives in the image's conda python only, so the run is a child
+    process under that interpreter (ctypes + numpy are all nsof.simulate needs); the golden stream and expected
+    state come from the reference itself (tests/golden/accum_sim_v2_split.npz)."""
+    import gzip
+    import json
+    import os
+    import subprocess
+    conda = "/opt/conda/bin/python3.9"
+    if not os.path.exists(conda) or subprocess.run([conda, "-c", "import h5py"], capture_output=True).returncode:
+        pytest.skip("no interpreter with h5py on this machine")
+    from conftest import PKG, golden_path
+    g = np.load(golden_path("accum_sim_v2_split.npz"))
+    h5 = tmp_path / "stream.hdf5"
+    script = f"""
+import sys, numpy as np, h5py
+sys.path.insert(0, {PKG!r})
+g = np.load({golden_path("accum_sim_v2_split.npz")!r})
+with h5py.File({str(h5)!r}, "w") as f:
+    ev = f.create_group("CD").create_group("events")
+    for k, dt in (("x", np.int16), ("y", np.int16), ("p", np.int8), ("t", np.int64)):
+        ev.create_dataset(k, data=g[k].astype(dt))
+from nsof.accumulator import load_events, simulate
+x, y, p, t, H, W = load_events({str(h5)!r})
+assert (H, W) == (int(g["y"].max()) + 1, int(g["x"].max()) + 1) and np.array_equal(t, g["t"]) and p.dtype.kind == "i"
+out = simulate({str(h5)!r}, version=2, slice_us=int(g["slice_us"]), active_v=float(g["active_v"]),
+               silent_v=float(g["silent_v"]), polarity="split")
+print("ok", out["w_final"].shape)
+"""
+    r = subprocess.run([conda, "-c", script], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, NSOF_HIP_RUNTIME="system"))
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    a = np.load(tmp_path / "stream.V2.npz")
+    b = np.load(tmp_path / "stream.V2_b.npz")
+    H, W = a["w_final"].shape
+    assert g["w_final"].shape == (H, W)
+    assert np.abs(a["w_final"] - g["w_final"]).max() <= W_ATOL and np.abs(b["w_final"] - g["w_final_b"]).max() <= W_ATOL
+    assert a["resistances"].dtype == np.float32 and a["resistances"].shape[0] == int(g["n_snapshots"])
+    with gzip.open(tmp_path / "stream.V2.json.gz", "rt") as fp:
+        meta = json.load(fp)
+    assert meta["version"] == 2 and meta["polarity"] == "split" and meta["refractory_us"] == 800
+    assert meta["scheme"] == "dc_bias_overlay" and meta["slice_us"] == int(g["slice_us"])

@@ -136,3 +136,17 @@ def test_generate_synthetic_events_matches_reference_output():
             assert np.array_equal(got, g[f"{name}_{key}"]), (name, key)
     x, y, p, t = generate_synthetic_events(duration_s=0.0)
     assert x.size == y.size == p.size == t.size == 0
+
+
+def test_flowviz_matches_reference_goldens(nsof_lib):
+    """Outputs of the reference's own flow_viz.py (tests/golden/gen_flowviz_golden.py ran it) reproduced byte for
+    byte: colour wheel, RGB / BGR order, clip_flow, float32 and float64 inputs, all-zero and tiny flows."""
+    from conftest import golden_path
+    from nsof import flowviz
+    with np.load(golden_path("flowviz_golden.npz")) as z:
+        assert np.array_equal(flowviz.make_colorwheel(), z["colorwheel"])
+        for name in ("smooth", "noise", "tiny", "zero", "f64"):
+            flow = z[f"{name}_flow"]
+            assert np.array_equal(flowviz.flow_to_image(flow), z[f"{name}_rgb"]), name
+            assert np.array_equal(flowviz.flow_to_image(flow, convert_to_bgr=True), z[f"{name}_bgr"]), name
+            assert np.array_equal(flowviz.flow_to_image(flow, clip_flow=2.5), z[f"{name}_clip"]), name
