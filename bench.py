@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--e2e-pairs", type=int, default=128,
                     help="pairs of the host-to-host (PCIe-inclusive) leg, rank 0 at N=1 only; 0 = skip")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the joined events -> accumulator -> flow leg (BASELINE config 5) and its accumulator record")
     ap.add_argument("--no-fast-leg", action="store_true",
                     help="skip the extra leg that times the opt-in float polynomial expansion (NSOF_OPT_POLYEXP_F32)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
@@ -229,6 +231,8 @@ def main():
         if world == 1 and prof and args.mode == "pairs" and not args.no_fast_leg:
             out.update(fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of=roof,
                                         prof=prof, steps=max(2, min(args.steps, 5))))
+        if world == 1 and not args.no_config5 and args.mode == "pairs":
+            out.update(config5_leg(nsof, torch, local_rank))
         if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
             out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
@@ -273,6 +277,63 @@ def fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg
         "option": "NSOF_OPT_POLYEXP_F32=1 (opt-in; default path is the exact one)", "value": round(n * steps / dt, 2),
         "unit": "pairs/s", "max_abs_epe_vs_exact_path": diff,
         "pairs_above_1e-4": int((per_pair > 1e-4).sum().item()), "pairs": n}}
+
+
+def config5_leg(nsof, torch, local_rank):
+    """BASELINE config 5 joined, on one GPU: synthetic 3840x2160 stream @ 1 M events/s ->
+    dense scheme-1 accumulator update of every 1 ms slice (events uploaded once) -> every 33 slices the surface as an
+    8-bit frame -> Farneback (params A) between consecutive surface frames; nothing leaves HBM in between.
+    "accumulator": slices/s with the roofline on SURVEY's definition (8 B/px/slice + 16 B/event: one read + one
+    write of w per slice) and on the bytes the fused design actually has to move (per 33 slices: two passes of
+    w read + w write + slice-mask read = 12 B/px, one surface pass 4 + 1 B/px, 4 B/event), the CPU oracle's rate
+    for the same slices (1 thread / all cores) and the state parity after the sampled slices."""
+    import numpy as np
+    from nsof import pipeline, synth
+    from oracle import oracle as O  # noqa: N812
+    H, W, every = 2160, 3840, 33  # noqa: N806
+    x, y, p, t = synth.make_event_stream_4k()
+    out = {}
+    with nsof.Context(local_rank) as c:
+        tm = {}
+        pipeline.events_to_flow_sequence(x, y, p, t, (H, W), snapshot_every=every, ctx=c, timings=tm)   # warm-up
+        frames, flows = pipeline.events_to_flow_sequence(x, y, p, t, (H, W), snapshot_every=every, ctx=c, timings=tm)
+        finite = bool(torch.isfinite(flows).all().item())
+        n_sl, n_fr = tm["slices"], tm["frames"]
+        rate = n_sl / tm["accumulator_s"]
+        npx, n_ev = H * W, int((t < n_sl * 1000 + t[0]).sum())
+        survey_bytes = 8.0 * npx * n_sl + 16.0 * n_ev
+        fused_bytes = (n_sl / every) * (2 * 12.0 + 5.0) * npx + 4.0 * n_ev
+        # parity + CPU rate on a bounded sample: the first k slices through the CPU oracle
+        k = 20
+        model, logical, physical, usable = O.host_cpu()
+        cpu1, w_ref = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=k, n_threads=1)
+        cpua, _ = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=k, n_threads=usable)
+        acc = nsof.Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=c, dense=True)
+        idx = nsof.accumulator.slice_index_array(t, 1000)
+        acc.set_events(x, y, p, t, idx)
+        acc.run(0, k)
+        werr = float(np.abs(acc.w() - w_ref).max())
+        acc.close()
+        out["accumulator"] = {
+            "value": round(rate, 1), "unit": "slices/s", "workload": f"{W}x{H} sensor, 1 M events/s, 1 ms slices, dense "
+            f"scheme-1 update of every slice + a surface frame every {every} slices; events uploaded once",
+            "slices": n_sl, "events": n_ev, "x_realtime": round(rate / 1000.0, 1),
+            "roofline_survey_definition": {"bytes_per_slice": round(survey_bytes / n_sl), "achieved": round(survey_bytes / tm["accumulator_s"] / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(survey_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3),
+                                           "note": "8 B/px/slice + 16 B/event; the fused pass replays 32 slices per read+write of w, so this exceeds 1"},
+            "roofline_fused_bytes": {"bytes_per_slice": round(fused_bytes / n_sl), "achieved": round(fused_bytes / tm["accumulator_s"] / 1e9, 1),
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fused_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3)},
+            "cpu_baseline": {"value": round(cpu1, 2), "value_all_cores": round(cpua, 2), "unit": "slices/s", "cores": 1,
+                             "cores_all": usable, "cpu_model": model, "kind": "port",
+                             "sample": f"first {k} slices, oracle/accum_ref.c (gcc -O3 -march=native, OpenMP over pixels)"},
+            "max_abs_w_vs_oracle": werr, "w_tolerance": 5e-7, "parity_ok": bool(werr <= 5e-7)}
+        out["config5"] = {"workload": "events -> accumulator -> surface frames -> Farneback A at 3840x2160, one GPU",
+                          "surface_frames": n_fr, "accumulator_ms": round(tm["accumulator_s"] * 1e3, 2),
+                          "flow_ms": round(tm["flow_s"] * 1e3, 2),
+                          "flow_pairs_per_s_4k": round((n_fr - 1) / tm["flow_s"], 1),
+                          "stream_seconds_per_wall_second": round((n_sl / 1000.0) / (tm["accumulator_s"] + tm["flow_s"]), 2),
+                          "flow_finite": finite}
+    return out
 
 
 def e2e_leg(nsof, p, prevs, nexts, flow, k, local_rank):

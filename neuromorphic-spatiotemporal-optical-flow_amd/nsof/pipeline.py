@@ -45,6 +45,51 @@ def events_to_rois(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slic
     return out
 
 
+def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, active_v=-6.0, silent_v=0.0,
+                            snapshot_every=33, dense=True, ctx=None, timings=None):
+    """BASELINE config 5 as one device-resident pipeline: event stream -> dense scheme-1 accumulator update of every
+    slice -> every ``snapshot_every`` slices the surface as an 8-bit frame (``Accumulator.surface_u8``: the reference's
+    current -> gray map, optical_flow_seg.py:426-431) -> Farneback flow between consecutive surface frames
+    (``farneback_sequence``: every frame's pyramid and expansion computed once).  Events are uploaded once; frames and
+    flow never leave HBM.  Returns ``(frames uint8 [n][H][W], flows float32 [n-1][H][W][2])`` as torch CUDA tensors.
+    ``timings`` (a dict) receives the wall time of the two stages."""
+    import time
+
+    import torch
+
+    from .context import default_context
+    from .farneback import PARAMS_A, farneback_sequence
+    ctx = ctx or default_context()
+    params = params or PARAMS_A
+    H, W = sensor_hw  # noqa: N806
+    dev = torch.device("cuda", ctx.device)
+    idx = slice_index_array(t, slice_us)
+    n_slices = len(idx) - 1
+    n_frames = n_slices // snapshot_every
+    if n_frames < 2:
+        raise ValueError("the stream is shorter than two snapshots")
+    frames = torch.empty((n_frames, H, W), dtype=torch.uint8, device=dev)
+    flows = torch.empty((n_frames - 1, H, W, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    acc = Accumulator(H, W, 1, "split", active_v, silent_v, ctx=ctx, dense=dense)
+    try:
+        acc.set_events(x, y, p, t, idx)
+        t0 = time.perf_counter()
+        for k in range(n_frames):
+            acc.run(k * snapshot_every, snapshot_every)
+            acc.surface_u8(frames[k])
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        farneback_sequence(frames, flows, n_frames, H, W, params, ctx=ctx)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+    finally:
+        acc.close()
+    if timings is not None:
+        timings.update(accumulator_s=t1 - t0, flow_s=t2 - t1, slices=n_frames * snapshot_every, frames=n_frames)
+    return frames, flows
+
+
 def gated_flow(gray_map, prev, nxt, cfg, flow_fn=None):
     """Flow of a frame pair restricted to the ROI(s) the gating map selects (``opticalFlow3D`` of the reference)."""
     kw = {} if flow_fn is None else {"flow_fn": flow_fn}

@@ -77,3 +77,22 @@ def make_events(seed, width=1280, height=720, n_background=200_000, duration_us=
     order = np.argsort(t, kind="stable")
     return (x[order].astype(np.int16), y[order].astype(np.int16), p[order].astype(np.int8),
             t[order].astype(np.int64))
+
+
+def make_event_stream_4k(seed=5, width=3840, height=2160, n_events=1_000_000, duration_us=1_000_000,
+                         window=(400, 300), window_share=0.3, speed_pps=600.0):
+    """The roofline-run stream of SURVEY.md section 8d config 5: ``n_events`` events over ``duration_us`` on a
+    ``width`` x ``height`` sensor, sorted by time; x, y uniform except for ``window_share`` of the events, which fall
+    into a ``window`` drifting left to right at ``speed_pps`` px/s; p ~ Bernoulli(0.5).  Schema of /CD/events."""
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.integers(0, duration_us, n_events)).astype(np.int64)
+    x = rng.integers(0, width, n_events)
+    y = rng.integers(0, height, n_events)
+    inside = rng.random(n_events) < window_share
+    ww, wh = window
+    x0 = (t * 1e-6 * speed_pps).astype(np.int64) % max(width - ww, 1)
+    y0 = (height - wh) // 2
+    x = np.where(inside, x0 + rng.integers(0, ww, n_events), x)
+    y = np.where(inside, y0 + rng.integers(0, wh, n_events), y)
+    p = (rng.random(n_events) < 0.5).astype(np.int8)
+    return x.astype(np.int16), y.astype(np.int16), p, t

@@ -50,9 +50,32 @@ static inline float update_one(float w, float V)
     return wn < 0.f ? 0.f : (wn > 1.f ? 1.f : wn);
 }
 
+/* Threads of the dense passes below: 1 unless the OpenMP build (`make perf`, bench.py's all-cores CPU leg) raises it. */
+static int g_threads = 1;
+void nsof_ref_set_threads(int n) { g_threads = n > 1 ? n : 1; }
+
 void nsof_ref_accum_update_state(const float* w, const float* V, float* out, size_t n)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
     for (size_t i = 0; i < n; i++) out[i] = update_one(w[i], V[i]);
+}
+
+/* One time slice of scheme 1 as the reference runs it (event_mem_sim.py:208-220): V = silent_v everywhere, active_v at
+ * the slice's event pixels, then the dense update -- the unit bench.py's CPU leg times (slices/s). */
+void nsof_ref_accum_slice_v1(float* w, float* V, size_t npx, const int16_t* x, const int16_t* y, int64_t n_ev, int W,
+                             float active_v, float silent_v)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (size_t i = 0; i < npx; i++) V[i] = silent_v;
+    for (int64_t e = 0; e < n_ev; e++) V[(size_t)y[e] * W + x[e]] = active_v;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
+    for (size_t i = 0; i < npx; i++) w[i] = update_one(w[i], V[i]);
 }
 
 /* resistance_exp (:60-63): lam = log(Roff/Ron) (float64 scalar); exp argument and exp in

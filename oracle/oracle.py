@@ -151,6 +151,32 @@ def perf_lib():
     return _perf
 
 
+def accum_slices_per_s(x, y, t, H, W, slice_us=1000, active_v=-6.0, silent_v=0.0, n_slices=20, n_threads=1):
+    """CPU rate of the reference's scheme-1 slice (V fill + event scatter + dense update_state over H x W) through the
+    perf build: the first ``n_slices`` slices of the stream, ``n_threads`` OpenMP threads.  Returns (slices/s, w)."""
+    import time
+    l = perf_lib()
+    l.nsof_ref_set_threads.argtypes = [C.c_int]
+    l.nsof_ref_accum_slice_v1.restype = None
+    l.nsof_ref_accum_slice_v1.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                          C.c_float, C.c_float]
+    x = np.ascontiguousarray(x, np.int16)
+    y = np.ascontiguousarray(y, np.int16)
+    idx = accum_slice_bounds(np.ascontiguousarray(t, np.int64), slice_us)
+    n_slices = min(n_slices, len(idx) - 1)
+    w = np.full((H, W), 0.5, np.float32)
+    V = np.empty((H, W), np.float32)
+    l.nsof_ref_set_threads(int(n_threads))
+    t0 = time.perf_counter()
+    for s in range(n_slices):
+        lo, hi = int(idx[s]), int(idx[s + 1])
+        l.nsof_ref_accum_slice_v1(w.ctypes.data, V.ctypes.data, w.size, x[lo:].ctypes.data, y[lo:].ctypes.data, hi - lo, W,
+                                  active_v, silent_v)
+    dt = time.perf_counter() - t0
+    l.nsof_ref_set_threads(1)
+    return n_slices / dt, w
+
+
 def farneback_many(prevs, nexts, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags=0, n_threads=1):
     """[n][H][W] uint8 x2 -> [n][H][W][2] float32 through the perf build, ``n_threads`` pairs at a time."""
     prevs, nexts = np.ascontiguousarray(prevs, np.uint8), np.ascontiguousarray(nexts, np.uint8)
