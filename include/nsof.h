@@ -210,10 +210,13 @@ int nsof_accum_step_events(nsof_accum* acc, const int16_t* x, const int16_t* y, 
 int nsof_accum_set_events(nsof_accum* acc, const int16_t* x, const int16_t* y, const int8_t* p,
                           const int64_t* t, const int64_t* slice_bounds, int64_t n_slices);
 int nsof_accum_run(nsof_accum* acc, int64_t first_slice, int64_t n_slices, int64_t snap_every);
-/* The current surface as an 8-bit frame on the DEVICE: g = uint8(clip(-3366/log10(I) - 306, 0, 255)), I = 1/R,
- * R = resistance_exp(w) -- the reference's map from device current to the gating image (optical_flow_seg.py:
- * 426-431) applied per pixel.  d_out uint8 [H][row_stride].  Asynchronous on the context's stream. */
-int nsof_accum_surface_u8_dev(nsof_accum* acc, int which, uint8_t* d_out, ptrdiff_t row_stride);
+/* The current surface as an 8-bit frame on the DEVICE, d_out uint8 [H][row_stride]; asynchronous on the context's
+ * stream.  mode NSOF_SURFACE_CURRENT: g = uint8(clip(-3366/log10(I) - 306, 0, 255)), I = 1/R, R = resistance_exp(w) --
+ * the reference's map from device current to the gating image (optical_flow_seg.py:426-431) applied per pixel
+ * (calibrated for arrays that start at w = 0; the event simulator's initial w = 0.5 already gives 255).
+ * mode NSOF_SURFACE_STATE: g = uint8(255 * w), the build-defined frame of the joined events -> flow pipeline. */
+enum { NSOF_SURFACE_CURRENT = 0, NSOF_SURFACE_STATE = 1 };
+int nsof_accum_surface_u8_dev(nsof_accum* acc, int which, int mode, uint8_t* d_out, ptrdiff_t row_stride);
 /* Checkpoint / resume (the reference persists only w_final, event_mem_sim.py:289-303): copy one array's state to /
  * from HOST memory -- w float32 [H][W], the refractory map int64 [H][W] (scheme 2; zeros otherwise) and the global
  * slice counter that times the snapshots.  NULL pointers are skipped. */

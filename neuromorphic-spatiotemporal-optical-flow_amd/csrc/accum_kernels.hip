@@ -283,16 +283,26 @@ __global__ __launch_bounds__(64) void k_frame_step(const double* __restrict__ a,
     res[i] = RON / exp(-lambda * (1 - ww));
 }
 
-// Temporal-prior surface as an 8-bit frame: the reference's bridge from device state to the gating input,
-// g = uint8(clip(-3366 / log10(I) - 306, 0, 255)) with I = V_ds / R, V_ds = 1 V (optical_flow_seg.py:426-431,
-// simulationcode_v4_transistor_uav.m:36), evaluated per pixel in double on R = resistance_exp(w) as float32.
+// Temporal-prior surface as an 8-bit frame.
+//   mode 0  the reference's bridge from device state to the gating input, g = uint8(clip(-3366 / log10(I) - 306, 0,
+//           255)) with I = V_ds / R, V_ds = 1 V (optical_flow_seg.py:426-431, simulationcode_v4_transistor_uav.m:36),
+//           evaluated per pixel in double on R = resistance_exp(w) as float32.  Calibrated for arrays that start at
+//           w = 0: the event simulator's initial state w = 0.5 (I = 1.7 uA) already maps to 255.
+//   mode 1  build-defined linear map of the state itself, g = uint8(255 * w) (float32 product, truncated): the frame
+//           the joined events -> surface -> flow pipeline (BASELINE config 5) hands to the flow stage.
 __global__ __launch_bounds__(256) void k_surface_gray(const float* __restrict__ w, uint8_t* __restrict__ out, int W, int H,
-                                                       ptrdiff_t stride, float neg_lam)
+                                                       ptrdiff_t stride, float neg_lam, int mode)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
-    const double r = (double)resistance_one(w[(size_t)y * W + x], neg_lam);
-    double g = -3366.0 / log10(1.0 / r) - 306.0;
+    const float ww = w[(size_t)y * W + x];
+    double g;
+    if (mode == 0) {
+        const double r = (double)resistance_one(ww, neg_lam);
+        g = -3366.0 / log10(1.0 / r) - 306.0;
+    } else {
+        g = (double)(ww * 255.0f);
+    }
     g = g < 0.0 ? 0.0 : (g > 255.0 ? 255.0 : g);   // NaN (I == 1 A exactly) cannot occur for R in [Ron, Roff]
     out[(ptrdiff_t)y * stride + x] = (uint8_t)g;
 }
@@ -606,14 +616,14 @@ extern "C" int nsof_accum_run(nsof_accum* a, int64_t first_slice, int64_t n_slic
     return accum_advance(a, first_slice, n_slices, snap_every);
 }
 
-extern "C" int nsof_accum_surface_u8_dev(nsof_accum* a, int which, uint8_t* d_out, ptrdiff_t row_stride)
+extern "C" int nsof_accum_surface_u8_dev(nsof_accum* a, int which, int mode, uint8_t* d_out, ptrdiff_t row_stride)
 {
-    if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W) return NSOF_EINVAL;
+    if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W || mode < 0 || mode > 1) return NSOF_EINVAL;
     nsof_ctx* ctx = a->ctx;
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     const float neg_lam = (float)(-std::log(ROFF / RON));
     dim3 grid((a->W + 255) / 256, a->H);
-    hipLaunchKernelGGL(k_surface_gray, grid, dim3(256), 0, ctx->stream, a->w[which], d_out, a->W, a->H, row_stride, neg_lam);
+    hipLaunchKernelGGL(k_surface_gray, grid, dim3(256), 0, ctx->stream, a->w[which], d_out, a->W, a->H, row_stride, neg_lam, mode);
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
 }

@@ -321,11 +321,11 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
     nsof_pipe* pp;
     if (int rc = pipe_get(ctx, &pp)) return rc;
 
-    // chunks of the list: about 256 MiB of flow (16 pairs of 1920x1080) each -- small enough that upload, compute
-    // and download of neighbouring chunks overlap for lists of a few dozen frames, large enough that the work list
+    // chunks of the list: about 512 MiB of flow (32 pairs of 1920x1080) each -- small enough that upload, compute
+    // and download of neighbouring chunks overlap for lists of a hundred frames, large enough that the work list
     // of a chunk still fills the GPU (the download, not the compute, bounds the pipeline: 16.6 MB per 1080p pair)
     const char* chunk_env = getenv("NSOF_PIPE_CHUNK_MB");   // tests shrink it to force several chunks
-    const size_t budget = (size_t)std::max(1l, chunk_env ? atol(chunk_env) : 256l) << 20;
+    const size_t budget = (size_t)std::max(1l, chunk_env ? atol(chunk_env) : 512l) << 20;
     std::vector<Chunk> chunks;
     for (int i = 0; i < n_pairs;) {
         Chunk c;

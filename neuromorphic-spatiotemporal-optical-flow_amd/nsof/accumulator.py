@@ -187,9 +187,12 @@ class Accumulator:
         self.ctx.check(self.ctx._lib.nsof_accum_run(self._p, int(first_slice), int(n_slices), int(snap_every)),
                        "accum_run")
 
-    def surface_u8(self, d_out, which=0, row_stride=None):
-        """The current surface as an 8-bit frame written to DEVICE memory (torch uint8 tensor / address)."""
-        self.ctx.check(self.ctx._lib.nsof_accum_surface_u8_dev(self._p, which, dev_ptr(d_out),
+    def surface_u8(self, d_out, which=0, row_stride=None, mode="state"):
+        """The current surface as an 8-bit frame written to DEVICE memory (torch uint8 tensor / address).
+        ``mode``: "current" = the reference's current -> gray map (optical_flow_seg.py:426-431; saturates at 255 for
+        w >= 0.42), "state" = uint8(255 * w)."""
+        self.ctx.check(self.ctx._lib.nsof_accum_surface_u8_dev(self._p, which, {"current": 0, "state": 1}[mode],
+                                                               dev_ptr(d_out),
                                                                self.W if row_stride is None else int(row_stride)),
                        "accum_surface_u8")
 

@@ -48,8 +48,9 @@ def events_to_rois(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slic
 def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, active_v=-6.0, silent_v=0.0,
                             snapshot_every=33, dense=True, ctx=None, timings=None):
     """BASELINE config 5 as one device-resident pipeline: event stream -> dense scheme-1 accumulator update of every
-    slice -> every ``snapshot_every`` slices the surface as an 8-bit frame (``Accumulator.surface_u8``: the reference's
-    current -> gray map, optical_flow_seg.py:426-431) -> Farneback flow between consecutive surface frames
+    slice -> every ``snapshot_every`` slices the surface as an 8-bit frame (``Accumulator.surface_u8``, mode "state":
+    uint8(255 * w) -- the reference's current -> gray map saturates for the simulator's w >= 0.5 and the reference has
+    no surface -> frame step of its own) -> Farneback flow between consecutive surface frames
     (``farneback_sequence``: every frame's pyramid and expansion computed once).  Events are uploaded once; frames and
     flow never leave HBM.  Returns ``(frames uint8 [n][H][W], flows float32 [n-1][H][W][2])`` as torch CUDA tensors.
     ``timings`` (a dict) receives the wall time of the two stages."""

@@ -264,26 +264,31 @@ def test_staged_events_and_resume(nsof_lib, ctx, version, polarity):
 
 
 def test_surface_u8_matches_host_map(nsof_lib, ctx, torch_dev):
-    """nsof_accum_surface_u8_dev == the reference's current -> gray map (optical_flow_seg.py:426-431) applied on the host
-    to the resistances the accumulator reports: identical but for the last-ulp of log10 at integer boundaries."""
+    """nsof_accum_surface_u8_dev: mode "current" == the reference's current -> gray map (optical_flow_seg.py:426-431)
+    applied on the host to the resistances the accumulator reports (identical but for the last ulp of log10 at integer
+    boundaries); mode "state" == uint8(255 * w) exactly.  A leaking run (silent_v above von) brings w below the 0.42
+    where the reference's map leaves saturation."""
     import torch
     from nsof import gating, synth
     W, H = 160, 120
     x, y, p, t = synth.make_events(9, W, H, 30000, 200_000, box=(30, 20))
     idx = nsof_lib.accumulator.slice_index_array(t, 1000)
-    acc = nsof_lib.Accumulator(H, W, 1, "split", -8.0, 0.0, ctx=ctx)
+    acc = nsof_lib.Accumulator(H, W, 1, "split", -8.0, 3.0, ctx=ctx)
     acc.step(x, y, p, t, idx)
-    out = torch.zeros((H, W + 16), dtype=torch.uint8, device=torch_dev)
+    out = torch.zeros((2, H, W + 16), dtype=torch.uint8, device=torch_dev)
     torch.cuda.synchronize()
-    acc.surface_u8(out, row_stride=W + 16)
+    acc.surface_u8(out[0], row_stride=W + 16, mode="current")
+    acc.surface_u8(out[1], row_stride=W + 16, mode="state")
     ctx.synchronize()
     got = out.cpu().numpy()
+    w = acc.w()
     want = gating.current_to_gray(1.0 / acc.resistance().astype(np.float64))
     acc.close()
-    assert not got[:, W:].any()
-    d = np.abs(got[:, :W].astype(np.int32) - want.astype(np.int32))
-    assert d.max() <= 1 and (d > 0).mean() < 1e-4
-    assert want.max() > want.min()        # the box left a visible trace
+    assert not got[:, :, W:].any()
+    d = np.abs(got[0, :, :W].astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    assert want.max() > want.min() and want.min() < 255
+    assert np.array_equal(got[1, :, :W], (w * np.float32(255.0)).astype(np.uint8))
 
 
 def test_row_bands_with_real_accumulator(nsof_lib, ctx):
