@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--params", choices=["A", "B", "C"], default="A")
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
-    ap.add_argument("--e2e-pairs", type=int, default=128,
+    ap.add_argument("--e2e-pairs", type=int, default=256,
                     help="pairs of the host-to-host (PCIe-inclusive) leg, rank 0 at N=1 only; 0 = skip")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the joined events -> accumulator -> flow leg (BASELINE config 5) and its accumulator record")
@@ -307,7 +307,11 @@ def config5_leg(nsof, torch, local_rank):
         k = 20
         model, logical, physical, usable = O.host_cpu()
         cpu1, w_ref = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=k, n_threads=1)
-        cpua, _ = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=k, n_threads=usable)
+        cpua, ta = 0.0, usable
+        for nt in sorted({usable, min(usable, 16)}, reverse=True):   # see cpu_leg: a box's CPU share may be smaller
+            v, _ = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=k, n_threads=nt)
+            if v > cpua:
+                cpua, ta = v, nt
         acc = nsof.Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=c, dense=True)
         idx = nsof.accumulator.slice_index_array(t, 1000)
         acc.set_events(x, y, p, t, idx)
@@ -324,8 +328,9 @@ def config5_leg(nsof, torch, local_rank):
             "roofline_fused_bytes": {"bytes_per_slice": round(fused_bytes / n_sl), "achieved": round(fused_bytes / tm["accumulator_s"] / 1e9, 1),
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fused_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3)},
             "cpu_baseline": {"value": round(cpu1, 2), "value_all_cores": round(cpua, 2), "unit": "slices/s", "cores": 1,
-                             "cores_all": usable, "cpu_model": model, "kind": "port",
-                             "sample": f"first {k} slices, oracle/accum_ref.c (gcc -O3 -march=native, OpenMP over pixels)"},
+                             "cores_all": ta, "cpu_model": model, "kind": "port",
+                             "sample": f"first {k} slices, oracle/accum_ref.c (gcc -O3 -march=native, OpenMP over pixels; "
+                                       f"best of {usable} and 16 threads)"},
             "max_abs_w_vs_oracle": werr, "w_tolerance": 5e-7, "parity_ok": bool(werr <= 5e-7)}
         out["config5"] = {"workload": "events -> accumulator -> surface frames -> Farneback A at 3840x2160, one GPU",
                           "surface_frames": n_fr, "accumulator_ms": round(tm["accumulator_s"] * 1e3, 2),
@@ -349,7 +354,7 @@ def e2e_leg(nsof, p, prevs, nexts, flow, k, local_rank):
     out = {}
     with nsof.Context(local_rank) as c2:
         pinned = [nsof.pinned_empty((h, w, 2), np.float32) for _ in range(k)]
-        nsof.farneback_pairs(pairs[:min(k, 64)], p, pinned[:min(k, 64)], ctx=c2)        # warm-up: staging, workspace
+        nsof.farneback_pairs(pairs, p, pinned, ctx=c2)        # warm-up: staging slots, workspace, page faults
         best = None
         for _ in range(2):
             t0 = time.perf_counter()
@@ -420,16 +425,22 @@ def cpu_leg(nsof, p, prevs, nexts, flow, k):
         t0 = time.perf_counter()
         refs = O.farneback_many(hp, hn, *args, n_threads=1)
         v1 = k / (time.perf_counter() - t0)
-        ka = max(k, min(4 * usable, prevs.shape[0]))            # all-cores leg: a few pairs per thread
-        hpa, hna = (hp, hn) if ka == k else (prevs[:ka].cpu().numpy(), nexts[:ka].cpu().numpy())
-        t0 = time.perf_counter()
-        O.farneback_many(hpa, hna, *args, n_threads=usable)
-        va = ka / (time.perf_counter() - t0)
+        # all-cores leg: OpenMP over pairs.  A box may expose more logical CPUs than its share lets a process use
+        # (oversubscribed threads only thrash), so a 16-thread run is timed as well and the better one reported.
+        va, ta, ka = 0.0, usable, k
+        for nt in sorted({usable, min(usable, 16)}, reverse=True):
+            kk = max(k, min(2 * nt, prevs.shape[0]))            # a couple of pairs per thread
+            hpa, hna = (hp, hn) if kk == k else (prevs[:kk].cpu().numpy(), nexts[:kk].cpu().numpy())
+            t0 = time.perf_counter()
+            O.farneback_many(hpa, hna, *args, n_threads=nt)
+            v = kk / (time.perf_counter() - t0)
+            if v > va:
+                va, ta, ka = v, nt, kk
         err = max(float(np.abs(refs[i] - gf[i]).max()) for i in range(k))
         out["cpu_baseline"] = dict(base, value=round(v1, 4), cores=1, kind="port",
-                                   value_all_cores=round(va, 4), cores_all=usable,
+                                   value_all_cores=round(va, 4), cores_all=ta,
                                    sample=f"first {k} pairs of the timed batch on 1 thread, first {ka} pairs on "
-                                          f"{usable} threads (OpenMP over pairs); CPU oracle oracle/farneback_ref.c "
+                                          f"{ta} threads (OpenMP over pairs; best of {usable} and 16 threads); CPU oracle oracle/farneback_ref.c "
                                           f"built gcc -O3 -march=native -ffp-contract=off on this host; restatement, "
                                           f"not OpenCV (cv2 is not importable on this image)")
         out["max_abs_epe_vs_oracle"] = err

@@ -124,6 +124,22 @@ def host_cpu():
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = logical
+    # a container's CPU share (cgroup quota) is what "all cores" can really use: more threads than that only thrash
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda s: s.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda s: [s.strip(), None])):
+        try:
+            with open(path) as f:
+                q, per = parse(f.read())
+            if per is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = f.read().strip()
+            if q not in ("max", "-1") and int(per) > 0:
+                usable = max(1, min(usable, -(-int(q) // int(per))))
+            break
+        except (OSError, ValueError):
+            continue
+    if os.environ.get("NSOF_CPU_THREADS"):
+        usable = max(1, int(os.environ["NSOF_CPU_THREADS"]))
     return model, logical, (len(phys) or logical), usable
 
 
