@@ -33,3 +33,13 @@ def test_bench_json_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     assert d["max_abs_epe_vs_oracle"] <= d["epe_tolerance"]
+    # round-2 records: host-to-host rate, opt-in float expansion, accumulator + joined config-5 pipeline
+    e = d["e2e"]
+    assert e["unit"] == "pairs/s" and e["value"] > 0 and e["identical_to_device_resident"] is True
+    f = d["fast_mode"]
+    assert f["value"] > 0 and 0 <= f["max_abs_epe_vs_exact_path"] < 0.5 and d["roofline_polyexp_fast"]["frac"] > 0
+    a = d["accumulator"]
+    assert a["unit"] == "slices/s" and a["value"] > 0 and a["parity_ok"] is True and a["cpu_baseline"]["value"] > 0
+    assert a["roofline_fused_bytes"]["frac"] > 0 and a["roofline_survey_definition"]["bytes_per_slice"] > 6e7
+    assert d["config5"]["flow_finite"] is True and d["config5"]["surface_frames"] >= 2
+    assert d["parity_ok"] is True
