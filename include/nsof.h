@@ -57,7 +57,12 @@ int nsof_synchronize(nsof_ctx* ctx);
  * from the default (exact) path by the end-point error DESIGN.md reports.  Applies to the uniform-shape entry points;
  * the work-list entries always run the exact kernel.  New contexts take the default from the environment
  * variable NSOF_POLYEXP_F32. */
-enum { NSOF_OPT_POLYEXP_F32 = 1 };
+/* NSOF_OPT_EXACT_ROWSUMS (default 0): 1 = the box-filter row sums are formed as the reference library forms them, one
+ * running double-precision sum along each image row, instead of per pixel -- the only place where the default path
+ * leaves the library's operation order.  Same numbers to ~1e-16; where the 2x2 system is rank deficient (real footage,
+ * small windows) that decides the flow's 4th decimal, and this mode then equals the CPU oracle bit for bit (about
+ * half the throughput; the matrices and column sums go through HBM).  Environment default: NSOF_EXACT_ROWSUMS. */
+enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);
 

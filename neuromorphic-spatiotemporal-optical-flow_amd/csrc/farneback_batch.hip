@@ -75,7 +75,7 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
         if (int rc = validate_desc(ctx, i, descs[i], p)) return rc;
 
     // Items the work-list kernels cover: fused iteration available (window 2..15, >= 1 iteration, at least 2x2 px).
-    const bool het_params = p.iterations >= 1 && p.winsize / 2 >= 1 && p.winsize / 2 <= 7;
+    const bool het_params = p.iterations >= 1 && p.winsize / 2 >= 1 && p.winsize / 2 <= 7 && !ctx->opt_exact_rowsums;
     std::vector<int> het, rest;
     for (int i = 0; i < n; i++)
         (het_params && nsof_iterate_supported(p.winsize, descs[i].width, descs[i].height) ? het : rest).push_back(i);

@@ -137,6 +137,7 @@ extern "C" int nsof_create(int device, nsof_ctx** out)
     }
     ctx->stream = ctx->own_stream;
     if (const char* e = getenv("NSOF_POLYEXP_F32")) ctx->opt_polyexp_f32 = (e[0] && e[0] != '0') ? 1 : 0;
+    if (const char* e = getenv("NSOF_EXACT_ROWSUMS")) ctx->opt_exact_rowsums = (e[0] && e[0] != '0') ? 1 : 0;
     *out = ctx;
     return NSOF_OK;
 }
@@ -180,6 +181,10 @@ extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
         ctx->opt_polyexp_f32 = value ? 1 : 0;
         return NSOF_OK;
     }
+    if (option == NSOF_OPT_EXACT_ROWSUMS) {
+        ctx->opt_exact_rowsums = value ? 1 : 0;
+        return NSOF_OK;
+    }
     return nsof_set_error(ctx, NSOF_EINVAL, "unknown option %d", option);
 }
 
@@ -188,6 +193,10 @@ extern "C" int nsof_get_option(const nsof_ctx* ctx, int option, int* value)
     if (!ctx || !value) return NSOF_EINVAL;
     if (option == NSOF_OPT_POLYEXP_F32) {
         *value = ctx->opt_polyexp_f32;
+        return NSOF_OK;
+    }
+    if (option == NSOF_OPT_EXACT_ROWSUMS) {
+        *value = ctx->opt_exact_rowsums;
         return NSOF_OK;
     }
     return NSOF_EINVAL;
@@ -448,6 +457,19 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     if (rc) return rc;
     if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const bool exact = ctx->opt_exact_rowsums != 0;
+    if (exact && (sequence || n_pairs > 8)) {
+        // the exact order keeps 40 B/px of column sums in HBM: run it 8 pairs at a time (a sequence as its pairs)
+        const uint8_t* nx = sequence ? d_prev + pair_stride : d_next;
+        for (int i = 0; i < n_pairs; i += 8) {
+            const int nb = n_pairs - i < 8 ? n_pairs - i : 8;
+            rc = nsof_farneback_core(ctx, false, nb, d_prev + (ptrdiff_t)i * pair_stride, nx + (ptrdiff_t)i * pair_stride,
+                                     row_stride, pair_stride, width, height, d_flow + (size_t)i * width * height * 2,
+                                     pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags);
+            if (rc) return rc;
+        }
+        return NSOF_OK;
+    }
 
     nsof_poly_taps ptaps;
     if ((rc = nsof_host_poly_taps(poly_n, poly_sigma, &ptaps))) return nsof_set_error(ctx, rc, "poly taps");
@@ -460,15 +482,17 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // Fused or unfused is decided once for the whole pyramid (inputs below 2x2 take the unfused pair).
     // NSOF_FUSED=0 forces the unfused pair (A/B runs; measured slower even for a lone 1080p pair: 6.1 vs 4.0 ms).
     static const char* fused_env = getenv("NSOF_FUSED");
-    const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0');
+    const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0') && !exact;
     const size_t szI = align_up(n_img * n0 * 4, 256), szR = align_up(n_img * 5 * n0 * 4, 256);
     const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
-    if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM))) return rc;
+    const size_t szV = exact ? align_up(B * 5 * n0 * 8, 256) : 0;   // transposed column sums of the exact order
+    if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM + szV))) return rc;
     char* base = (char*)ctx->ws;
     float* dI = (float*)base;
     float* dR = (float*)(base + szI);
     float* dS = (float*)(base + szI + szR);
     float* dM = (float*)(base + szI + szR + szS);
+    double* dV = (double*)(base + szI + szR + szS + szM);
     // Two flow buffers, A = the caller's output and S = scratch; every level uses their leading B*nk pixels.
     // Each upsample and each fused iteration moves the flow to the other buffer, so the buffer the coarsest
     // level starts in is chosen such that the last iteration of level 0 writes A.
@@ -533,7 +557,9 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
             float* flow = fb[cur];
             if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
             for (int it = 0; it < iterations; it++) {
-                if ((rc = nsof_launch_blur_solve(ctx, n_pairs, dM, wk, hk, winsize, flow))) return rc;
+                if (exact) rc = nsof_launch_blur_solve_exact(ctx, n_pairs, dM, wk, hk, winsize, dV, flow);
+                else rc = nsof_launch_blur_solve(ctx, n_pairs, dM, wk, hk, winsize, flow);
+                if (rc) return rc;
                 if (it < iterations - 1)
                     if ((rc = nsof_launch_update_matrices(ctx, n_pairs, R0, R1, 5 * nk, flow, wk, hk, dM))) return rc;
             }

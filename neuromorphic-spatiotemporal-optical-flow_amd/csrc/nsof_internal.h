@@ -25,6 +25,7 @@ struct nsof_ctx {
     unsigned prof_mask = 0;
     nsof_prof_slot prof[NSOF_K_COUNT];
     int opt_polyexp_f32 = 0;   // NSOF_OPT_POLYEXP_F32
+    int opt_exact_rowsums = 0; // NSOF_OPT_EXACT_ROWSUMS
     char err[512] = {0};
     // reusable device workspace of the Farneback driver
     void* ws = nullptr;
@@ -136,6 +137,9 @@ int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H
 int nsof_launch_update_matrices(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                                 const float* flow, int W, int H, float* M);
 int nsof_launch_blur_solve(nsof_ctx* ctx, int n_pairs, const float* M, int W, int H, int winsize, float* flow);
+// The same in the reference library's exact summation order; VT: n_pairs * 5 * W * H doubles of scratch.
+int nsof_launch_blur_solve_exact(nsof_ctx* ctx, int n_pairs, const float* M, int W, int H, int winsize, double* VT,
+                                 float* flow);
 int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw,
                               int dh, float mul);
 bool nsof_iterate_supported(int winsize, int W, int H);

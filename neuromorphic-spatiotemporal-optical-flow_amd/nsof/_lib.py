@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSOF_LIB", os.path.join(_HERE, "libnsof.so"))   # NSOF_LIB: A/B builds of the same ABI
 
 OPT_POLYEXP_F32 = 1
+OPT_EXACT_ROWSUMS = 2
 NSOF_OK, NSOF_EINVAL, NSOF_ESHAPE, NSOF_EDEVICE, NSOF_ENOMEM, NSOF_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_SEGMENT, K_MORPH, K_REMAP, K_SSIM, K_COUNT = range(12)
 

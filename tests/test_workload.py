@@ -296,3 +296,50 @@ def test_roi_batch_is_cheaper_than_one_by_one(nsof_lib, ctx, torch_dev):
     ctx.synchronize()
     per_pair_ms = (time.perf_counter() - t0) / 5 / 64 * 1e3
     assert per_pair_ms < 0.1, per_pair_ms
+
+
+@pytest.mark.gpu
+def test_exact_rowsum_order_equals_oracle_on_real_frames(nsof_lib, ctx, oracle, stacks):
+    """NSOF_OPT_EXACT_ROWSUMS: with the box-filter row sums formed in the library's order (one running sum per image
+    row) the HIP path equals the CPU oracle BIT FOR BIT on the reference's real frames too -- the 801x801 autodriving
+    pair with the 3x3 window of parameter set B, where the default path differs by up to 7.8e-4 at 80 pixels -- through
+    the per-call entry, the uniform batch and the work list."""
+    pil = pytest.importorskip("PIL.Image")
+    import torch
+    from nsof import _lib, gating
+    nsof = nsof_lib
+    d = os.path.join(GOLDEN, "frames", "autodriving")
+    fr = [gating.frame_to_gray(np.ascontiguousarray(np.asarray(pil.open(os.path.join(d, f"{k}.jpg")).convert("RGB"))[..., ::-1]),
+                               "RGB2GRAY") for k in (1, 2, 3)]
+    B = (0.6, 3, 3, 3, 10, 1.05, 0)
+    p = nsof.FarnebackParams(*B)
+    refs = [oracle.farneback(fr[i], fr[i + 1], *B) for i in range(2)]
+    default = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
+    assert 1e-4 < float(np.abs(default - refs[0]).max()) < 2e-3          # the documented deviation of the default path
+    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
+    try:
+        assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1
+        one = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
+        lst = nsof.farneback_pairs([(fr[0], fr[1]), (fr[1], fr[2]), (fr[0][100:400, 50:700], fr[1][100:400, 50:700])], p, ctx=ctx)
+        dev = torch.device("cuda", 0)
+        frames = torch.from_numpy(np.stack(fr)).to(dev)
+        flows = torch.empty((2, 801, 801, 2), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        nsof.farneback_sequence(frames, flows, 3, 801, 801, p, ctx=ctx)
+        ctx.synchronize()
+    finally:
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
+    assert np.array_equal(one, refs[0])
+    assert np.array_equal(lst[0], refs[0]) and np.array_equal(lst[1], refs[1])
+    assert np.array_equal(lst[2], oracle.farneback(np.ascontiguousarray(fr[0][100:400, 50:700]),
+                                                   np.ascontiguousarray(fr[1][100:400, 50:700]), *B))
+    assert np.array_equal(flows.cpu().numpy(), np.stack(refs))
+    # parameter set A on the synthetic pair: exact too (and the default path already is)
+    from nsof import synth
+    a, b = synth.make_pair(3, 270, 480)
+    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
+    try:
+        ex = nsof.calcOpticalFlowFarneback(a, b, None, *A, ctx=ctx)
+    finally:
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
+    assert np.array_equal(ex, oracle.farneback(a, b, *A))
