@@ -231,12 +231,17 @@ def main():
         if world == 1 and prof and args.mode == "pairs" and not args.no_fast_leg:
             out.update(fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of=roof,
                                         prof=prof, steps=max(2, min(args.steps, 5))))
+        if world == 1 and args.mode == "pairs" and not args.no_fast_leg:
+            out.update(exact_mode_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, h, w))
         if world == 1 and not args.no_config5 and args.mode == "pairs":
             out.update(config5_leg(nsof, torch, local_rank))
         if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
             out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
+            exact_check(out, nsof, p, prevs, nexts)
+        if "exact_mode" in out:
+            out["exact_mode"].pop("_flow_for_cpu_check", None)
         print(json.dumps(out))
         if out.get("parity_ok") is False:
             print(f"bench: GPU flow differs from the CPU baseline by more than {out['epe_tolerance']}", file=sys.stderr)
@@ -339,6 +344,27 @@ def config5_leg(nsof, torch, local_rank):
                           "stream_seconds_per_wall_second": round((n_sl / 1000.0) / (tm["accumulator_s"] + tm["flow_s"]), 2),
                           "flow_finite": finite}
     return out
+
+
+def exact_mode_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, h, w, k=32):
+    """NSOF_OPT_EXACT_ROWSUMS (opt-in): the box-filter row sums in the reference library's own order -- the one place
+    where the default path differs from it (by ~1e-16 relative in double; invisible on these frames, up to ~1e-3 px at
+    rank-deficient windows of real footage).  Rate on the first k pairs and the distance to the default result."""
+    k = min(k, prevs.shape[0])
+    out = torch.empty((k, h, w, 2), dtype=torch.float32, device=flow.device)
+    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
+    try:
+        nsof.farneback_batch(prevs[:k], nexts[:k], out, k, h, w, p, ctx=ctx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nsof.farneback_batch(prevs[:k], nexts[:k], out, k, h, w, p, ctx=ctx)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
+    return {"exact_mode": {"option": "NSOF_OPT_EXACT_ROWSUMS=1 (opt-in)", "value": round(k / dt, 1), "unit": "pairs/s",
+                           "pairs": k, "max_abs_vs_default_path": float((out - flow[:k]).abs().max().item()),
+                           "_flow_for_cpu_check": out[:2].cpu().numpy()}}
 
 
 def e2e_leg(nsof, p, prevs, nexts, flow, k, local_rank):
@@ -447,6 +473,20 @@ def cpu_leg(nsof, p, prevs, nexts, flow, k):
     out["epe_tolerance"] = 1e-4
     out["parity_ok"] = bool(err < 1e-4)
     return out
+
+
+def exact_check(out, nsof, p, prevs, nexts):
+    """The exact-order flow of the first two pairs against the CPU oracle: bit for bit."""
+    import numpy as np
+    from oracle import oracle as O  # noqa: N812
+    ex = out.get("exact_mode")
+    if not ex:
+        return
+    got = ex.pop("_flow_for_cpu_check")
+    args = [getattr(p, a) for a in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    hp, hn = prevs[:got.shape[0]].cpu().numpy(), nexts[:got.shape[0]].cpu().numpy()
+    ex["bit_identical_to_oracle"] = bool(all(np.array_equal(O.farneback(hp[i], hn[i], *args), got[i])
+                                             for i in range(got.shape[0])))
 
 
 if __name__ == "__main__":
