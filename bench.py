@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8, help="pairs timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--e2e-pairs", type=int, default=256,
                     help="pairs of the host-to-host (PCIe-inclusive) leg, rank 0 at N=1 only; 0 = skip")
+    ap.add_argument("--io", choices=["none", "gather"], default="none",
+                    help="gather: after the headline run, an extra leg in which rank 0 owns every frame pair: frames go "
+                         "to the ranks and flow comes back point to point over RCCL/xGMI, chunked and overlapped with "
+                         "compute (nsof.dist.run_sharded_overlapped); printed as 'io_gather' next to the headline")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the joined events -> accumulator -> flow leg (BASELINE config 5) and its accumulator record")
     ap.add_argument("--no-fast-leg", action="store_true",
@@ -176,6 +180,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    io_rec = None
+    if args.io == "gather" and args.mode == "pairs":
+        io_rec = io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w, prevs, nexts)
+
     prof = {}
     if not args.no_prof:
         for k in kernel_ids:
@@ -210,6 +218,8 @@ def main():
                        "mode": args.mode, "pairs_per_gpu_per_step": n, "global_pairs_per_step": n * world,
                        "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
         }
+        if io_rec:
+            out["io_gather"] = io_rec
         if prof:
             dom = max(kernel_ids, key=lambda k: prof[k][0])
             out["roofline"] = roof(dom)
@@ -344,6 +354,52 @@ def config5_leg(nsof, torch, local_rank):
                           "stream_seconds_per_wall_second": round((n_sl / 1000.0) / (tm["accumulator_s"] + tm["flow_s"]), 2),
                           "flow_finite": finite}
     return out
+
+
+def io_gather_leg(nsof, torch, dist, ctx, p, dev, rank, world, n, h, w, prevs, nexts, chunk=32):
+    """Rank 0 owns all world*n frame pairs (it replicates its own batch): scatter -> compute -> gather with
+    nsof.dist.run_sharded_overlapped (RCCL send/recv per peer, chunks of `chunk` pairs, copies overlapped with
+    compute).  Whole-job pairs/s including both transfers; at world == 1 nothing moves."""
+    from nsof import dist as nd
+    n_total = n * world
+    if rank == 0:
+        prev_all = prevs.repeat(world, 1, 1) if world > 1 else prevs
+        next_all = nexts.repeat(world, 1, 1) if world > 1 else nexts
+    else:
+        prev_all = next_all = None
+
+    def compute(pv, nx):
+        k = pv.shape[0]
+        o = torch.empty((k, h, w, 2), dtype=torch.float32, device=dev)
+        nsof.farneback_batch(pv.contiguous(), nx.contiguous(), o, k, h, w, p, ctx=ctx)
+        return o
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if dist is None:      # single process: the same code path needs a (1-rank) process group
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        nd.run_sharded_overlapped(prev_all, next_all, n_total, (h, w), dev, compute, chunk=chunk)   # warm-up
+        sync()
+        t0 = time.perf_counter()
+        out = nd.run_sharded_overlapped(prev_all, next_all, n_total, (h, w), dev, compute, chunk=chunk)
+        sync()
+        dt = time.perf_counter() - t0
+    finally:
+        if dist is None:
+            tdist.destroy_process_group()
+    if rank != 0:
+        return None
+    return {"value": round(n_total / dt, 1), "unit": "pairs/s", "pairs": n_total, "chunk_pairs": chunk,
+            "path": "rank 0 -> send/recv frames -> compute on every rank -> send/recv flow -> rank 0 (RCCL over xGMI)",
+            "bytes_moved_per_pair": 2 * h * w + 8 * h * w if world > 1 else 0,
+            "flow_checksum": float(out[::max(1, n_total // 8)].double().abs().sum().item())}
 
 
 def exact_mode_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, h, w, k=32):

@@ -88,6 +88,61 @@ def run_sharded(prev_all, next_all, n_total, shape, device, compute, src=0):
     return gather_flows(flow, n_total, dst=src)
 
 
+def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, chunk=32, src=0):
+    """scatter -> compute -> gather as a three-stage pipeline over chunks of every rank's shard, point to point
+    (``dist.batch_isend_irecv``: ncclSend/ncclRecv pairs under RCCL, one xGMI link per peer) instead of the padded
+    ``dist.scatter`` / ``dist.gather`` through rank ``src``: in round k the frames of chunk k travel to the peers while
+    chunk k-1 computes and the flow of chunk k-2 travels back, so the links and the GPUs are busy together and no rank
+    ever holds more than two chunks of staging.  Rank ``src`` computes its own shard in place.
+
+    ``prev_all`` / ``next_all``: uint8 [n_total, H, W] on rank ``src`` (ignored elsewhere); ``compute(prev, next) ->
+    float32 [n, H, W, 2]`` on ``device``.  Returns float32 [n_total, H, W, 2] on rank ``src``, None elsewhere."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bounds = shard_bounds(n_total, world)
+    h, w = shape
+    chunks = [[(c, min(c + chunk, hi)) for c in range(lo, hi, chunk)] for lo, hi in bounds]   # per rank: [(a, b)]
+    rounds = max(len(c) for c in chunks)
+    out = torch.empty((n_total, h, w, 2), dtype=torch.float32, device=device) if rank == src else None
+    frames = [None, None]      # peers: double-buffered (prev, next) chunk
+    flows = [None, None]       # peers: double-buffered flow chunk
+    my = chunks[rank]
+    for k in range(rounds + 2):
+        ops, post = [], []
+        # stage A: frames of chunk k leave rank src
+        if rank == src:
+            for r in range(world):
+                if r != src and k < len(chunks[r]):
+                    a, b = chunks[r][k]
+                    ops.append(dist.P2POp(dist.isend, prev_all[a:b].to(device).contiguous(), r))
+                    ops.append(dist.P2POp(dist.isend, next_all[a:b].to(device).contiguous(), r))
+        elif k < len(my):
+            a, b = my[k]
+            buf = torch.empty((2, b - a, h, w), dtype=torch.uint8, device=device)
+            frames[k & 1] = buf
+            ops.append(dist.P2POp(dist.irecv, buf[0], src))
+            ops.append(dist.P2POp(dist.irecv, buf[1], src))
+        # stage C: flow of chunk k-2 returns to rank src
+        if rank == src:
+            for r in range(world):
+                if r != src and 0 <= k - 2 < len(chunks[r]):
+                    a, b = chunks[r][k - 2]
+                    ops.append(dist.P2POp(dist.irecv, out[a:b], r))
+        elif 0 <= k - 2 < len(my):
+            ops.append(dist.P2POp(dist.isend, flows[k & 1], src))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        # stage B: chunk k-1 computes while the copies above are in flight
+        if 0 <= k - 1 < len(my):
+            a, b = my[k - 1]
+            if rank == src:
+                out[a:b] = compute(prev_all[a:b].to(device), next_all[a:b].to(device))
+            else:
+                f = frames[(k - 1) & 1]
+                flows[(k - 1) & 1] = compute(f[0], f[1]).contiguous()
+        for q in reqs:
+            q.wait()
+    return out
+
+
 # ---- accumulator: row bands (SURVEY.md section 8e) --------------------------------------------------------------
 def band_bounds(height, world):
     """Row band [y0, y1) of every rank: pixels are independent, so the H x W state splits by rows with no halo."""

@@ -41,6 +41,12 @@ def _worker(rank, world, port, n_total, ret):
 
     out = nd.run_sharded(prev, nxt, n_total, (h, wd), "cpu", compute)
     assert seen["n"] == hi - lo
+    # the chunked, point-to-point, overlapped variant gives the same field (chunks of 2 pairs: several rounds)
+    out2 = nd.run_sharded_overlapped(prev, nxt, n_total, (h, wd), "cpu", _fake_flow, chunk=2)
+    if rank == 0:
+        assert torch.equal(out2, out)
+    else:
+        assert out2 is None
     t = nd.max_over_ranks(1.0 + rank)
     assert t == float(world)
     if rank == 0:
