@@ -180,15 +180,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    io_rec = None
-    if args.io == "gather" and args.mode == "pairs":
-        io_rec = io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w, prevs, nexts)
-
     prof = {}
     if not args.no_prof:
         for k in kernel_ids:
             prof[k] = ctx.prof_collect(k)
         ctx.prof_enable()
+
+    io_rec = None
+    if args.io == "gather" and args.mode == "pairs":
+        io_rec = io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w, prevs, nexts)
 
     exit_code = 0
     if rank == 0:
