@@ -117,6 +117,13 @@ def main():
                          "per-frame work is shared between neighbouring pairs (nsof_farneback_u8_sequence_dev)")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout, whatever libraries print: RCCL writes a version banner to stdout when a process
+    # group comes up.  Everything else that lands on file descriptor 1 is sent to stderr; the JSON line goes to the
+    # real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -252,7 +259,8 @@ def main():
             exact_check(out, nsof, p, prevs, nexts)
         if "exact_mode" in out:
             out["exact_mode"].pop("_flow_for_cpu_check", None)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if out.get("parity_ok") is False:
             print(f"bench: GPU flow differs from the CPU baseline by more than {out['epe_tolerance']}", file=sys.stderr)
             exit_code = 3
