@@ -817,10 +817,13 @@ __device__ __forceinline__ void q_producer_loop(float (*mring)[5][COLS], const P
     }
 }
 
-template <int MH, int COLS>
+// VOUT: instead of forming the row sums and solving, the column sums of the strip's own columns go to HBM
+// (Vout: [H][5][W] doubles of this pair) -- phase A of the exact-order path, see k_rowscan_solve below.
+template <int MH, int COLS, bool VOUT = false>
 __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
                                                 const Planes& R1, const FlowSrc<false>& F, float2* Fout, size_t fpitch,
-                                                int W, int H, int x0, int xc, int col, int nsteps, double scale)
+                                                int W, int H, int x0, int xc, int col, int nsteps, double scale,
+                                                double* Vout = nullptr)
 {
     using G = QGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, TPR = COLS / 4;   // TPR solve threads per row
@@ -855,6 +858,7 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double 
     const int hrow = col / TPR, t4 = col % TPR;   // solve phase: COLS/4 threads per row, 4 pixels each
     int slot_new = (2 * MH + 1) % RL;           // stream index m    -> slot 2m+1
     int slot_old = 0;                           // stream index -m-1 -> slot 0
+    const bool own = col >= MH && col < MH + SW && x0 + col - MH < W;   // VOUT: this thread's column belongs to the strip
     for (int t = 0; t < nsteps; t++) {
         // column sums: four more rows enter the window of this thread's column
 #pragma unroll
@@ -863,12 +867,21 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double 
             for (int c = 0; c < 5; c++) {
                 const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
                 vs[c] += (double)d;
-                sv[q][c][col] = vs[c];
+                if constexpr (VOUT) {
+                    if (own && 4 * t + q < H)
+                        __builtin_nontemporal_store(vs[c], Vout + ((size_t)(4 * t + q) * 5 + c) * W + (x0 + col - MH));
+                } else {
+                    sv[q][c][col] = vs[c];
+                }
             }
             slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
             slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
         }
         __syncthreads();   // B1(t): column sums of step t visible
+        if constexpr (VOUT) {
+            __syncthreads();   // B2(t): same barrier sequence as the solving variant
+            continue;
+        }
         const int yo = 4 * t + hrow, xo = x0 + 4 * t4;
         if (4 * t4 < SW && yo < H && xo < W) {
             const double (*svr)[COLS] = sv[hrow];
@@ -908,11 +921,12 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double 
     }
 }
 
-template <int MH, bool HET, int COLS = 256>
+template <int MH, bool HET, int COLS = 256, bool VOUT = false>
 __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict__ R0b, const float* __restrict__ R1b,
                                                     size_t pair_stride, const float* __restrict__ flow_in,
                                                     float* __restrict__ flow_out, int W, int H, int block_size,
-                                                    const nsof_het_item* __restrict__ items, int het_final)
+                                                    const nsof_het_item* __restrict__ items, int het_final,
+                                                    double* __restrict__ vsum_out = nullptr)
 {
     using G = QGeom<MH, COLS>;
     constexpr int SW = G::SW;
@@ -963,11 +977,143 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
     float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)pair * plane;
     const int nsteps = (H + 3) / 4;
     if (role == 0)
-        q_consumer_loop<MH, COLS>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps, 1. / (block_size * block_size));
+        q_consumer_loop<MH, COLS, VOUT>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps,
+                                        1. / (block_size * block_size), VOUT ? vsum_out + (size_t)pair * 5 * plane : nullptr);
     else if (role == 1)
         q_producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
     else
         q_producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact-order row sums, phase B: the reference library's running row sums + the 2x2 solve.
+//
+// The library forms the box filter's ROW sums as ONE running double-precision sum along each image row,
+// g += vsum[x+m] - vsum[x-m-1]; where the 2x2 system is rank deficient the rounding history of that sum decides the
+// flow's 4th decimal (and much more on degenerate frames), so bit-level parity needs this very order
+// (DESIGN.md section 2).  It is sequential along x over the whole row, hence a second kernel: phase A
+// (k_iterate_q<.., VOUT>) leaves the column sums in HBM, [H][5][W] doubles per pair; here a workgroup owns a band of
+// 64 rows and walks the image left to right in tiles of 8 columns:
+//   load   the tile's column sums -> an LDS ring of 32 columns (64-B row segments)
+//   scan   thread <-> (row, plane): 8 steps of the running sum, kept in a register, results -> LDS
+//   solve  thread <-> pixel of the 64 x 8 tile: the 2x2 solve, flow stored as 64-B row segments
+// The next tile's loads are in flight during the solve.  Same arithmetic as oracle/farneback_ref.c, bit for bit.
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_ROWS = 64, RS_TW = 8, RS_RING = 32, RS_VSTR = 33, RS_SSTR = 9;
+constexpr size_t RS_SMEM = sizeof(double) * 5 * RS_ROWS * (RS_VSTR + RS_SSTR);
+
+__global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict__ V, int W, int H, int m, int block_size,
+                                                       float* __restrict__ flow, size_t fpitch_default,
+                                                       const nsof_het_item* __restrict__ items, int het_final,
+                                                       const unsigned long long* __restrict__ voffs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rs[];
+    double (*Vw)[RS_ROWS][RS_VSTR] = reinterpret_cast<double (*)[RS_ROWS][RS_VSTR]>(smem_rs);                  // [5]
+    double (*St)[RS_ROWS][RS_SSTR] =
+        reinterpret_cast<double (*)[RS_ROWS][RS_SSTR]>(smem_rs + sizeof(double) * 5 * RS_ROWS * RS_VSTR);      // [5]
+    const int tid = threadIdx.x;
+    size_t fpitch = fpitch_default;
+    float2* Fout;
+    const double* Vp;
+    if (items) {   // work list: blockIdx.z indexes the level's item table
+        const nsof_het_item& it = items[blockIdx.z];
+        W = it.wk;
+        H = it.hk;
+        if (blockIdx.x * RS_ROWS >= H) return;
+        Vp = V + voffs[blockIdx.z];
+        if (het_final) {
+            Fout = reinterpret_cast<float2*>(it.out);
+            fpitch = (size_t)it.out_pitch;
+        } else {
+            Fout = reinterpret_cast<float2*>(flow) + it.offF;
+            fpitch = (size_t)W;
+        }
+    } else {
+        Vp = V + (size_t)blockIdx.z * 5 * W * H;
+        Fout = reinterpret_cast<float2*>(flow) + (size_t)blockIdx.z * W * H;
+    }
+    const int y0 = blockIdx.x * RS_ROWS;
+    const double scale = 1. / (block_size * block_size);
+    // loader: element e = tid + 320 i of an 8-column tile: column e % 8, row (e / 8) % 64, plane e / 512
+    auto load_cols = [&](int xa, double (&reg)[8]) {   // columns [xa, xa + 8) -> registers
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int e = tid + 320 * i;
+            const int cx = e & 7, r = (e >> 3) & 63, c = e >> 9;
+            const int y = min(y0 + r, H - 1), x = min(xa + cx, W - 1);
+            reg[i] = Vp[((size_t)y * 5 + c) * W + x];
+        }
+    };
+    auto store_cols = [&](int xa, const double (&reg)[8]) {   // columns beyond the image keep their slots' contents
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int e = tid + 320 * i;
+            const int cx = e & 7, r = (e >> 3) & 63, c = e >> 9;
+            if (xa + cx < W) Vw[c][r][(xa + cx) & (RS_RING - 1)] = reg[i];
+        }
+    };
+    // The scan of the tile at xt reads columns [xt - m - 1, xt + 7 + m] (clamped to the image); the ring holds
+    // [loaded - 32, loaded): loaded starts at 24 and grows by 8 per tile, so xt + 8 + m <= loaded <= xt + 31 - m (m <= 7).
+    double reg[8];
+    int loaded = 0;
+    for (int k = 0; k < 3; k++, loaded += RS_TW) {
+        load_cols(loaded, reg);
+        store_cols(loaded, reg);
+    }
+    __syncthreads();
+    const int sc = tid >> 6, sr = tid & 63;             // scan role: (plane, row)
+    auto col = [&](int x) { return Vw[sc][sr][min(max(x, 0), W - 1) & (RS_RING - 1)]; };
+    double S = col(0) * (m + 2);
+    for (int x = 1; x < m; x++) S += col(x);
+    for (int xt = 0; xt < W; xt += RS_TW) {
+        // scan: the library's running sum over this tile's columns
+#pragma unroll
+        for (int j = 0; j < RS_TW; j++) {
+            const int x = xt + j;
+            S += col(x + m) - col(x - m - 1);
+            St[sc][sr][j] = S;
+        }
+        __syncthreads();
+        // the next tile's 8 columns travel while this tile is solved; they overwrite slots of columns < loaded - 24 =
+        // xt - m - 1 at most ... which only the finished scan needed
+        const bool more = xt + RS_TW < W;
+        if (more) load_cols(loaded, reg);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = tid + 320 * i;
+            if (e < RS_ROWS * RS_TW) {
+                const int px = e & 7, r = e >> 3;
+                const int x = xt + px, y = y0 + r;
+                if (x < W && y < H) {
+                    const double g11 = St[0][r][px] * scale, g12 = St[1][r][px] * scale, g22 = St[2][r][px] * scale;
+                    const double h1 = St[3][r][px] * scale, h2 = St[4][r][px] * scale;
+                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    Fout[(size_t)y * fpitch + x] =
+                        make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                }
+            }
+        }
+        if (more) {
+            store_cols(loaded, reg);
+            loaded += RS_TW;
+        }
+        __syncthreads();
+    }
+}
+
+template <int MH>
+int launch_iterate_q_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                           const float* flow_in, float* flow_out, int W, int H, int winsize, double* vsum)
+{
+    using G = QGeom<MH>;
+    if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false, 256, true>, G::SMEM)) return rc;
+    if (int rc = lds_opt_in(ctx, k_rowscan_solve, RS_SMEM)) return rc;
+    dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
+    hipLaunchKernelGGL((k_iterate_q<MH, false, 256, true>), grid, dim3(768), G::SMEM, ctx->stream, R0, R1, pair_stride,
+                       flow_in, flow_out, W, H, winsize, nullptr, 0, vsum);
+    hipLaunchKernelGGL(k_rowscan_solve, dim3((H + RS_ROWS - 1) / RS_ROWS, 1, n_pairs), dim3(320), RS_SMEM, ctx->stream,
+                       (const double*)vsum, W, H, MH, winsize, flow_out, (size_t)W, nullptr, 0, nullptr);
+    return NSOF_OK;
 }
 
 template <int MH>
@@ -1198,6 +1344,34 @@ int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
         case 5: rc = launch_iterate_pc_het<5>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
         case 6: rc = launch_iterate_pc_het<6>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
         default: rc = launch_iterate_pc_het<7>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
+    }
+    if (rc) return rc;
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// Exact-order twin of nsof_launch_iterate: phase A (fused matrix update + column sums -> vsum) and phase B (row scan
+// + solve).  vsum: n_pairs * 5 * W * H doubles of scratch.  winsize 2..15.
+bool nsof_iterate_exact_supported(int winsize, int W, int H)
+{
+    const int m = winsize / 2;
+    return m >= 1 && m <= 7 && W >= 2 && H >= 2;
+}
+
+int nsof_launch_iterate_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                              const float* flow_in, float* flow_out, int W, int H, int winsize, double* vsum)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    int rc;
+    switch (winsize / 2) {
+        case 1: rc = launch_iterate_q_exact<1>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        case 2: rc = launch_iterate_q_exact<2>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        case 3: rc = launch_iterate_q_exact<3>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        case 4: rc = launch_iterate_q_exact<4>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        case 5: rc = launch_iterate_q_exact<5>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        case 6: rc = launch_iterate_q_exact<6>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        case 7: rc = launch_iterate_q_exact<7>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "exact-order fused iteration supports winsize 2..15");
     }
     if (rc) return rc;
     NSOF_HIP(ctx, hipGetLastError());

@@ -458,11 +458,17 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     const bool exact = ctx->opt_exact_rowsums != 0;
-    if (exact && (sequence || n_pairs > 8)) {
-        // the exact order keeps 40 B/px of column sums in HBM: run it 8 pairs at a time (a sequence as its pairs)
+    static const int exact_chunk = [] {
+        const char* e = getenv("NSOF_EXACT_CHUNK");
+        const int v = e ? atoi(e) : 64;
+        return v < 1 ? 1 : v;
+    }();
+    if (exact && (sequence || n_pairs > exact_chunk)) {
+        // the exact order keeps 40 B/px of column sums (+ 20 B/px of matrices) in HBM: 64 pairs of 1920x1080 at a time
+        // (8 GB) fill the GPU -- the row walk has one thread per image row; a sequence is run as its pairs
         const uint8_t* nx = sequence ? d_prev + pair_stride : d_next;
-        for (int i = 0; i < n_pairs; i += 8) {
-            const int nb = n_pairs - i < 8 ? n_pairs - i : 8;
+        for (int i = 0; i < n_pairs; i += exact_chunk) {
+            const int nb = n_pairs - i < exact_chunk ? n_pairs - i : exact_chunk;
             rc = nsof_farneback_core(ctx, false, nb, d_prev + (ptrdiff_t)i * pair_stride, nx + (ptrdiff_t)i * pair_stride,
                                      row_stride, pair_stride, width, height, d_flow + (size_t)i * width * height * 2,
                                      pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags);
@@ -482,7 +488,10 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // Fused or unfused is decided once for the whole pyramid (inputs below 2x2 take the unfused pair).
     // NSOF_FUSED=0 forces the unfused pair (A/B runs; measured slower even for a lone 1080p pair: 6.1 vs 4.0 ms).
     static const char* fused_env = getenv("NSOF_FUSED");
-    const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0') && !exact;
+    // exact row-sum order: the fused two-kernel form (phase A + row scan) where the window fits, else the unfused kernels
+    const bool exact_fused = exact && nsof_iterate_exact_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0');
+    const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0') &&
+                       (!exact || exact_fused);
     const size_t szI = align_up(n_img * n0 * 4, 256), szR = align_up(n_img * 5 * n0 * 4, 256);
     const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
     const size_t szV = exact ? align_up(B * 5 * n0 * 8, 256) : 0;   // transposed column sums of the exact order
@@ -502,7 +511,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // Measured on MI355X (1080p x 128 pairs): folding costs more in the producers (4 gathers + the resample per
     // row, 168 VGPRs) than the standalone resample kernel saves (24.6 -> 25.5 ms per step), so it is opt-in.
     static const bool fold_env = getenv("NSOF_FOLD_UPSAMPLE") != nullptr;
-    const bool fold_ups = fold_env && fused && iterations > 0 &&
+    const bool fold_ups = fold_env && fused && !exact && iterations > 0 &&
                           nsof_iterate_upsample_supported(winsize, width, height);
     const int flips = fused ? (fold_ups ? (L + 1) * iterations : L * (1 + iterations) + iterations) : L;
     int cur = flips & 1;
@@ -548,6 +557,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
                 if (it == 0 && pending_ups)
                     rc = nsof_launch_iterate_upsample(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], pw, ph,
                                                       (float)(1. / pyr_scale), fb[cur ^ 1], wk, hk, winsize);
+                else if (exact_fused)
+                    rc = nsof_launch_iterate_exact(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize, dV);
                 else
                     rc = nsof_launch_iterate(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize);
                 if (rc) return rc;

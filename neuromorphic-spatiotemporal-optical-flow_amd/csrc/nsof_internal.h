@@ -146,6 +146,11 @@ bool nsof_iterate_supported(int winsize, int W, int H);
 // Fused iteration; flow_in != flow_out.
 int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                         const float* flow_in, float* flow_out, int W, int H, int winsize);
+// Exact-order twin (row sums as one running sum per image row, the reference library's order): vsum = n_pairs * 5 * W * H
+// doubles of scratch (the column sums pass through HBM between its two kernels).
+bool nsof_iterate_exact_supported(int winsize, int W, int H);
+int nsof_launch_iterate_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                              const float* flow_in, float* flow_out, int W, int H, int winsize, double* vsum);
 bool nsof_iterate_upsample_supported(int winsize, int W, int H);
 // First iteration of a level: flow_in = resample(coarse_flow [sh][sw][2]) * mul, computed on the fly.
 int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
