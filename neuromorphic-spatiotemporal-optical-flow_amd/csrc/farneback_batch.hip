@@ -75,7 +75,8 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
         if (int rc = validate_desc(ctx, i, descs[i], p)) return rc;
 
     // Items the work-list kernels cover: fused iteration available (window 2..15, >= 1 iteration, at least 2x2 px).
-    const bool het_params = p.iterations >= 1 && p.winsize / 2 >= 1 && p.winsize / 2 <= 7 && !ctx->opt_exact_rowsums;
+    const bool het_params = p.iterations >= 1 && p.winsize / 2 >= 1 && p.winsize / 2 <= 7;
+    const bool exact = ctx->opt_exact_rowsums != 0;
     std::vector<int> het, rest;
     for (int i = 0; i < n; i++)
         (het_params && nsof_iterate_supported(p.winsize, descs[i].width, descs[i].height) ? het : rest).push_back(i);
@@ -151,11 +152,13 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
 
         // workspace: level images, expansions, two flow buffers (every level uses their leading part)
         const size_t szI = align_up(maxI * 4, 256), szR = align_up(maxR * 4, 256), szF = align_up(maxF * 8, 256);
-        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + 2 * szF))) return rc;
+        const size_t szV = exact ? szR : 0;   // exact order: column sums, 5 doubles per pixel = the expansion's footprint
+        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + 2 * szF + szV))) return rc;
         char* base = (char*)ctx->ws;
         float* dI = (float*)base;
         float* dR = (float*)(base + szI);
         float* fb[2] = {(float*)(base + szI + szR), (float*)(base + szI + szR + szF)};
+        double* dV = (double*)(base + szI + szR + 2 * szF);
         int cur = 0;
         for (int k = Lmax; k >= 0; k--) {
             int wk, hk, ks;
@@ -176,8 +179,12 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
             if ((rc = nsof_launch_polyexp_het(ctx, nk_items, dt, max_w[k], max_h[k], ptaps, dI, dR))) return rc;
             for (int it = 0; it < p.iterations; it++) {
                 const bool final = k == 0 && it == p.iterations - 1;
-                if ((rc = nsof_launch_iterate_het(ctx, nk_items, dt, max_w[k], dR, fb[cur], fb[cur ^ 1], final, p.winsize)))
-                    return rc;
+                if (exact)
+                    rc = nsof_launch_iterate_het_exact(ctx, nk_items, dt, max_w[k], max_h[k], dR, fb[cur], fb[cur ^ 1], final,
+                                                       p.winsize, dV);
+                else
+                    rc = nsof_launch_iterate_het(ctx, nk_items, dt, max_w[k], dR, fb[cur], fb[cur ^ 1], final, p.winsize);
+                if (rc) return rc;
                 cur ^= 1;
             }
         }

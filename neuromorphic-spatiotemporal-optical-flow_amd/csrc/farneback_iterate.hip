@@ -947,6 +947,7 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
         pair_stride = 0;
         pair = 0;
         flow_in += 2 * it.offF;
+        if constexpr (VOUT) vsum_out += it.offR / 2;
         if (het_final) {
             flow_out = it.out;
             fpitch = (size_t)it.out_pitch;
@@ -1004,8 +1005,7 @@ constexpr size_t RS_SMEM = sizeof(double) * 5 * RS_ROWS * (RS_VSTR + RS_SSTR);
 
 __global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict__ V, int W, int H, int m, int block_size,
                                                        float* __restrict__ flow, size_t fpitch_default,
-                                                       const nsof_het_item* __restrict__ items, int het_final,
-                                                       const unsigned long long* __restrict__ voffs)
+                                                       const nsof_het_item* __restrict__ items, int het_final)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rs[];
     double (*Vw)[RS_ROWS][RS_VSTR] = reinterpret_cast<double (*)[RS_ROWS][RS_VSTR]>(smem_rs);                  // [5]
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict_
         W = it.wk;
         H = it.hk;
         if (blockIdx.x * RS_ROWS >= H) return;
-        Vp = V + voffs[blockIdx.z];
+        Vp = V + it.offR / 2;   // an item's column sums (5 wk hk doubles) mirror its expansion block (10 wk hk floats)
         if (het_final) {
             Fout = reinterpret_cast<float2*>(it.out);
             fpitch = (size_t)it.out_pitch;
@@ -1112,7 +1112,22 @@ int launch_iterate_q_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const fl
     hipLaunchKernelGGL((k_iterate_q<MH, false, 256, true>), grid, dim3(768), G::SMEM, ctx->stream, R0, R1, pair_stride,
                        flow_in, flow_out, W, H, winsize, nullptr, 0, vsum);
     hipLaunchKernelGGL(k_rowscan_solve, dim3((H + RS_ROWS - 1) / RS_ROWS, 1, n_pairs), dim3(320), RS_SMEM, ctx->stream,
-                       (const double*)vsum, W, H, MH, winsize, flow_out, (size_t)W, nullptr, 0, nullptr);
+                       (const double*)vsum, W, H, MH, winsize, flow_out, (size_t)W, nullptr, 0);
+    return NSOF_OK;
+}
+
+template <int MH>
+int launch_iterate_q_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_item* items, int max_w, int max_h, const float* R,
+                               const float* flow_in, float* flow_out, bool final, int winsize, double* vsum)
+{
+    using G = QGeom<MH>;
+    if (int rc = lds_opt_in(ctx, k_iterate_q<MH, true, 256, true>, G::SMEM)) return rc;
+    if (int rc = lds_opt_in(ctx, k_rowscan_solve, RS_SMEM)) return rc;
+    dim3 grid((max_w + G::SW - 1) / G::SW, 1, n_items);
+    hipLaunchKernelGGL((k_iterate_q<MH, true, 256, true>), grid, dim3(768), G::SMEM, ctx->stream, R, R, (size_t)0, flow_in,
+                       flow_out, 0, 0, winsize, items, 0, vsum);
+    hipLaunchKernelGGL(k_rowscan_solve, dim3((max_h + RS_ROWS - 1) / RS_ROWS, 1, n_items), dim3(320), RS_SMEM, ctx->stream,
+                       (const double*)vsum, 0, 0, MH, winsize, flow_out, (size_t)0, items, final ? 1 : 0);
     return NSOF_OK;
 }
 
@@ -1372,6 +1387,24 @@ int nsof_launch_iterate_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const
         case 6: rc = launch_iterate_q_exact<6>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
         case 7: rc = launch_iterate_q_exact<7>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, vsum); break;
         default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "exact-order fused iteration supports winsize 2..15");
+    }
+    if (rc) return rc;
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// Work-list twin of nsof_launch_iterate_exact; vsum mirrors the level's expansion buffer (same size in bytes).
+int nsof_launch_iterate_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                                  const float* R, const float* flow_in, float* flow_out, bool final, int winsize,
+                                  double* vsum)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    int rc;
+    switch (winsize / 2) {
+#define NSOF_QHE(MM) case MM: rc = launch_iterate_q_het_exact<MM>(ctx, n_items, d_items, max_w, max_h, R, flow_in, flow_out, final, winsize, vsum); break
+        NSOF_QHE(1); NSOF_QHE(2); NSOF_QHE(3); NSOF_QHE(4); NSOF_QHE(5); NSOF_QHE(6); NSOF_QHE(7);
+#undef NSOF_QHE
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "exact-order work-list iteration supports winsize 2..15");
     }
     if (rc) return rc;
     NSOF_HIP(ctx, hipGetLastError());

@@ -118,6 +118,9 @@ struct nsof_het_item {
 };
 enum { NSOF_HET_VEC0 = 1 };
 
+int nsof_launch_iterate_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                                  const float* R, const float* flow_in, float* flow_out, bool final, int winsize,
+                                  double* vsum);
 // All launchers are asynchronous on ctx->stream and return an nsof_status.
 // The *_het twins take a device table of n_items entries; max_* are the largest extents over the table.
 int nsof_launch_prep_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
