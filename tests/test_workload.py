@@ -314,8 +314,9 @@ def test_exact_rowsum_order_equals_oracle_on_real_frames(nsof_lib, ctx, oracle, 
     B = (0.6, 3, 3, 3, 10, 1.05, 0)
     p = nsof.FarnebackParams(*B)
     refs = [oracle.farneback(fr[i], fr[i + 1], *B) for i in range(2)]
-    default = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
-    assert 1e-4 < float(np.abs(default - refs[0]).max()) < 2e-3          # the documented deviation of the default path
+    if not ctx.get_option(_lib.OPT_EXACT_ROWSUMS):                      # (NSOF_EXACT_ROWSUMS=1 makes it the default)
+        default = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
+        assert 1e-4 < float(np.abs(default - refs[0]).max()) < 2e-3      # the documented deviation of the default path
     ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
     try:
         assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1
