@@ -11,6 +11,8 @@
 //     canvas without a paste.  Arithmetic per item is that of the per-call path, bit for bit.
 //   * nsof_farneback_u8_batch: the same for HOST memory, as a three-stage pipeline over chunks of the list
 //     (upload of chunk c+1 and download of chunk c-1 on their own streams while chunk c computes).
+#include <sched.h>
+
 #include <algorithm>
 #include <array>
 #include <chrono>
@@ -195,6 +197,32 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
 }
 
 // ---- pipelined host entry ---------------------------------------------------------------------------------------
+// CPUs of a NUMA node (sysfs cpulist "0-63,128-191"), empty if unknown.
+std::vector<int> node_cpus(int node)
+{
+    std::vector<int> out;
+    if (node < 0) return out;
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return out;
+    int a, b;
+    char sep;
+    while (fscanf(f, "%d", &a) == 1) {
+        b = a;
+        if (fscanf(f, "%c", &sep) == 1 && sep == '-') {
+            if (fscanf(f, "%d", &b) != 1) b = a;
+            if (fscanf(f, "%c", &sep) != 1) sep = 0;
+        }
+        for (int c = a; c <= b; c++) out.push_back(c);
+        if (sep != ',') break;
+    }
+    fclose(f);
+    return out;
+}
+
+int g_pack_node = -1;   // NUMA node the packing threads prefer (set per call from the context's device)
+
 void parallel_rows(size_t n_tasks, const std::function<void(size_t)>& fn)
 {
     static const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -203,9 +231,22 @@ void parallel_rows(size_t n_tasks, const std::function<void(size_t)>& fn)
         for (size_t i = 0; i < n_tasks; i++) fn(i);
         return;
     }
+    static thread_local std::vector<int> cpus;
+    static thread_local int cpus_node = -2;
+    if (cpus_node != g_pack_node) {
+        cpus = node_cpus(g_pack_node);
+        cpus_node = g_pack_node;
+    }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)
         th.emplace_back([&, t] {
+            if (!cpus.empty()) {   // the staging buffers live on the GPU's node: copy from there (best effort)
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                for (int c : cpus)
+                    if (c < CPU_SETSIZE) CPU_SET(c, &set);
+                (void)sched_setaffinity(0, sizeof(set), &set);
+            }
             for (size_t i = t; i < n_tasks; i += nt) fn(i);
         });
     for (auto& x : th) x.join();
@@ -278,7 +319,8 @@ int grow_host(nsof_ctx* ctx, void** buf, size_t* cur, size_t need)
     if (*cur >= need) return NSOF_OK;
     if (*buf) NSOF_HIP(ctx, hipHostFree(*buf));
     *buf = nullptr; *cur = 0;
-    if (hipHostMalloc(buf, need, hipHostMallocDefault) != hipSuccess) { *buf = nullptr; return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu)", need); }
+    *buf = nsof_pinned_alloc(ctx->device, need);
+    if (!*buf) return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu)", need);
     *cur = need;
     return NSOF_OK;
 }
@@ -327,6 +369,7 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     nsof_pipe* pp;
     if (int rc = pipe_get(ctx, &pp)) return rc;
+    g_pack_node = nsof_gpu_numa_node(ctx->device);
 
     // chunks of the list: about 512 MiB of flow (32 pairs of 1920x1080) each -- small enough that upload, compute
     // and download of neighbouring chunks overlap for lists of a hundred frames, large enough that the work list
@@ -513,12 +556,12 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
 
 extern "C" void* nsof_host_alloc(size_t bytes)
 {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
         (void)hipGetLastError();
-        return nullptr;
+        dev = 0;
     }
-    return p;
+    return nsof_pinned_alloc(dev, bytes);   // on the current device's NUMA node where the host lets us choose
 }
 
 extern "C" void nsof_host_free(void* p)

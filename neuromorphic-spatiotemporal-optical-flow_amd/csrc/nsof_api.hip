@@ -2,10 +2,14 @@
 // The level loop mirrors the driver of the reference's flow backend
 // (cv2.calcOpticalFlowFarneback, called at /root/reference/optical_flow_seg.py:203):
 // coarsest level first, every level resampled from the blurred FULL-RES frame.
+#include <cctype>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "nsof_internal.h"
 
@@ -86,6 +90,48 @@ extern "C" int nsof_prof_collect(nsof_ctx* ctx, int id, double* total_ms, long l
     return NSOF_OK;
 }
 
+// ---- page-locked host memory next to the GPU ------------------------------------------------------------------
+// On a two-socket host a pinned buffer on the far socket halves the PCIe copy rate (measured on the MI355X boxes:
+// 28 instead of 57 GB/s).  The GPU's NUMA node comes from sysfs (PCI bus id -> numa_node); the allocation runs under
+// a temporary MPOL_PREFERRED policy for that node (hipHostMallocNumaUser makes the runtime honour it).  Every step
+// is best effort: without sysfs / the syscall the default placement is used.
+int nsof_gpu_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+void* nsof_pinned_alloc(int device, size_t bytes)
+{
+    void* p = nullptr;
+    const int node = nsof_gpu_numa_node(device);
+    bool policy = false;
+    if (node >= 0 && node < 1024) {
+        unsigned long mask[16] = {0};
+        mask[node / (8 * sizeof(unsigned long))] = 1ul << (node % (8 * sizeof(unsigned long)));
+        policy = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 8 * sizeof(mask) + 1) == 0;
+    }
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, policy ? hipHostMallocNumaUser : hipHostMallocDefault);
+    if (policy) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
 int nsof_hstage_reserve(nsof_ctx* ctx, size_t need)
 {
     if (ctx->hstage_bytes >= need) return NSOF_OK;
@@ -93,8 +139,8 @@ int nsof_hstage_reserve(nsof_ctx* ctx, size_t need)
     if (ctx->hstage) hipHostFree(ctx->hstage);
     ctx->hstage = nullptr;
     ctx->hstage_bytes = 0;
-    hipError_t e = hipHostMalloc(&ctx->hstage, need, hipHostMallocDefault);
-    if (e != hipSuccess) return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+    ctx->hstage = nsof_pinned_alloc(ctx->device, need);
+    if (!ctx->hstage) return nsof_set_error(ctx, NSOF_ENOMEM, "hipHostMalloc(%zu) failed", need);
     ctx->hstage_bytes = need;
     return NSOF_OK;
 }

@@ -52,6 +52,9 @@ struct nsof_ctx {
 
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
 int nsof_ws_reserve(nsof_ctx* ctx, void** buf, size_t* cur, size_t need);
+// Page-locked host memory on the GPU's NUMA node (best effort); NUMA node of a device from sysfs, -1 if unknown.
+void* nsof_pinned_alloc(int device, size_t bytes);
+int nsof_gpu_numa_node(int device);
 // Grow ctx->hstage (pinned host staging) to at least `need` bytes.
 int nsof_hstage_reserve(nsof_ctx* ctx, size_t need);
 
