@@ -124,6 +124,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see nsof/_lib.py: streams that share a hardware queue serialise
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
