@@ -61,7 +61,7 @@ int nsof_synchronize(nsof_ctx* ctx);
  * running double-precision sum along each image row, instead of per pixel -- the only place where the default path
  * leaves the library's operation order.  Same numbers to ~1e-16; where the 2x2 system is rank deficient (real footage,
  * small windows) that decides the flow's 4th decimal, and this mode then equals the CPU oracle bit for bit (about
- * half the throughput; the matrices and column sums go through HBM).  Environment default: NSOF_EXACT_ROWSUMS. */
+ * half the throughput: the column sums pass through HBM between two kernels).  Environment default: NSOF_EXACT_ROWSUMS. */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);
@@ -251,6 +251,20 @@ int nsof_accum_frames_f64(nsof_ctx* ctx, const double* imgs, int n_frames, int h
 /* slice_indices() of event_mem_sim.py:78-83 on a HOST timestamp array: returns the number
  * of bounds and fills idx (if not NULL) with up to cap entries. */
 int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t slice_us, int64_t* idx, int64_t cap);
+
+/* ---- ROI gating: the rectangles the gated path crops -------------------------------------------- */
+/* opticalFlow3D's gating arithmetic (optical_flow_seg.py:211-252 with :115-121, :426-435) for ONE gating slice, pure
+ * host code (maps are at most 24 x 13 cells): current [rows][cols] (device currents in ampere, the constructed3DMatrix
+ * slice) -> gray = uint8(clip(-3366/log10(I) - 306, 0, 255)) -> cells with gray >= thres inside the
+ * (frame_h / memsize) x (frame_w / memsize) transition picture -> connected components (connectivity 4 or 8, labelled
+ * in raster order of their first cell) -> per component (flag 1) or for the union box (flag 2) the rectangle
+ * x0 = max(x*memsize - extend_left, 0), y0 = max(y*memsize - extend_upper, 0), x1 = min((x+a)*memsize + extend_right,
+ * frame_w), y1 = min((y+b)*memsize + extend_lower, frame_h).  rects receives up to max_rects rows of (x0, y0, x1, y1);
+ * returns the number of rectangles (which may exceed max_rects: call again with more room), 0 when nothing crosses
+ * the threshold, or a negative nsof_status. */
+int nsof_roi_from_surface(const double* current, int rows, int cols, int frame_w, int frame_h, int memsize, int thres,
+                          int extend_left, int extend_right, int extend_upper, int extend_lower, int connectivity,
+                          int flag, int* rects, int max_rects);
 
 /* ---- next: motion-segmentation head on the flow field --------------------- */
 /* Replaces, in /root/reference/optical_flow_seg.py, the chain

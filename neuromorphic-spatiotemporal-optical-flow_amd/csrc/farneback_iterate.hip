@@ -994,16 +994,22 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
 // flow's 4th decimal (and much more on degenerate frames), so bit-level parity needs this very order
 // (DESIGN.md section 2).  It is sequential along x over the whole row, hence a second kernel: phase A
 // (k_iterate_q<.., VOUT>) leaves the column sums in HBM, [H][5][W] doubles per pair; here a workgroup owns a band of
-// 64 rows and walks the image left to right in tiles of 8 columns:
+// RS_ROWS rows and walks the image left to right in tiles of 8 columns:
 //   load   the tile's column sums -> an LDS ring of 32 columns (64-B row segments)
 //   scan   thread <-> (row, plane): 8 steps of the running sum, kept in a register, results -> LDS
 //   solve  thread <-> pixel of the 64 x 8 tile: the 2x2 solve, flow stored as 64-B row segments
 // The next tile's loads are in flight during the solve.  Same arithmetic as oracle/farneback_ref.c, bit for bit.
 // ---------------------------------------------------------------------------------------------
-constexpr int RS_ROWS = 64, RS_TW = 8, RS_RING = 32, RS_VSTR = 33, RS_SSTR = 9;
+#ifndef NSOF_RS_ROWS
+#define NSOF_RS_ROWS 32
+#endif
+constexpr int RS_ROWS = NSOF_RS_ROWS, RS_TW = 8, RS_RING = 32, RS_VSTR = 33, RS_SSTR = 9;
+constexpr int RS_THREADS = 5 * RS_ROWS;                      // thread <-> (plane, row) in the scan
+constexpr int RS_RSH = RS_ROWS == 64 ? 6 : 5;                // log2(RS_ROWS)
+static_assert(RS_ROWS == 32 || RS_ROWS == 64, "row band of 32 or 64 rows");
 constexpr size_t RS_SMEM = sizeof(double) * 5 * RS_ROWS * (RS_VSTR + RS_SSTR);
 
-__global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict__ V, int W, int H, int m, int block_size,
+__global__ __launch_bounds__(RS_THREADS) void k_rowscan_solve(const double* __restrict__ V, int W, int H, int m, int block_size,
                                                        float* __restrict__ flow, size_t fpitch_default,
                                                        const nsof_het_item* __restrict__ items, int het_final)
 {
@@ -1034,12 +1040,12 @@ __global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict_
     }
     const int y0 = blockIdx.x * RS_ROWS;
     const double scale = 1. / (block_size * block_size);
-    // loader: element e = tid + 320 i of an 8-column tile: column e % 8, row (e / 8) % 64, plane e / 512
+    // loader: element e = tid + RS_THREADS i of an 8-column tile: column e % 8, row (e / 8) % RS_ROWS, plane e / (8 RS_ROWS)
     auto load_cols = [&](int xa, double (&reg)[8]) {   // columns [xa, xa + 8) -> registers
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int e = tid + 320 * i;
-            const int cx = e & 7, r = (e >> 3) & 63, c = e >> 9;
+            const int e = tid + RS_THREADS * i;
+            const int cx = e & 7, r = (e >> 3) & (RS_ROWS - 1), c = e >> (3 + RS_RSH);
             const int y = min(y0 + r, H - 1), x = min(xa + cx, W - 1);
             reg[i] = Vp[((size_t)y * 5 + c) * W + x];
         }
@@ -1047,25 +1053,29 @@ __global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict_
     auto store_cols = [&](int xa, const double (&reg)[8]) {   // columns beyond the image keep their slots' contents
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const int e = tid + 320 * i;
-            const int cx = e & 7, r = (e >> 3) & 63, c = e >> 9;
+            const int e = tid + RS_THREADS * i;
+            const int cx = e & 7, r = (e >> 3) & (RS_ROWS - 1), c = e >> (3 + RS_RSH);
             if (xa + cx < W) Vw[c][r][(xa + cx) & (RS_RING - 1)] = reg[i];
         }
     };
     // The scan of the tile at xt reads columns [xt - m - 1, xt + 7 + m] (clamped to the image); the ring holds
-    // [loaded - 32, loaded): loaded starts at 24 and grows by 8 per tile, so xt + 8 + m <= loaded <= xt + 31 - m (m <= 7).
-    double reg[8];
-    int loaded = 0;
-    for (int k = 0; k < 3; k++, loaded += RS_TW) {
-        load_cols(loaded, reg);
-        store_cols(loaded, reg);
+    // [loaded - 32, loaded): loaded starts at 24 and grows by 8 per tile, so xt + 8 + m <= loaded <= xt + 32 (m <= 7).
+    // The ring has room for ONE tile of lookahead only, so the HBM latency is covered in registers: three sets of 8
+    // values per thread are in flight, a set is written to the ring three tiles after its loads were issued.
+    double regs[3][8];
+    for (int k = 0; k < 3; k++) {
+        load_cols(RS_TW * k, regs[0]);
+        store_cols(RS_TW * k, regs[0]);
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) load_cols(24 + RS_TW * k, regs[k]);   // columns of tiles +3, +4, +5 on their way
     __syncthreads();
-    const int sc = tid >> 6, sr = tid & 63;             // scan role: (plane, row)
+    const int sc = tid >> RS_RSH, sr = tid & (RS_ROWS - 1);   // scan role: (plane, row)
     auto col = [&](int x) { return Vw[sc][sr][min(max(x, 0), W - 1) & (RS_RING - 1)]; };
     double S = col(0) * (m + 2);
     for (int x = 1; x < m; x++) S += col(x);
-    for (int xt = 0; xt < W; xt += RS_TW) {
+    auto tile = [&](auto kc, int xt) {
+        constexpr int K = decltype(kc)::value;   // register set of this tile's refill
         // scan: the library's running sum over this tile's columns
 #pragma unroll
         for (int j = 0; j < RS_TW; j++) {
@@ -1074,13 +1084,9 @@ __global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict_
             St[sc][sr][j] = S;
         }
         __syncthreads();
-        // the next tile's 8 columns travel while this tile is solved; they overwrite slots of columns < loaded - 24 =
-        // xt - m - 1 at most ... which only the finished scan needed
-        const bool more = xt + RS_TW < W;
-        if (more) load_cols(loaded, reg);
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const int e = tid + 320 * i;
+            const int e = tid + RS_THREADS * i;
             if (e < RS_ROWS * RS_TW) {
                 const int px = e & 7, r = e >> 3;
                 const int x = xt + px, y = y0 + r;
@@ -1093,11 +1099,16 @@ __global__ __launch_bounds__(320) void k_rowscan_solve(const double* __restrict_
                 }
             }
         }
-        if (more) {
-            store_cols(loaded, reg);
-            loaded += RS_TW;
-        }
+        // columns [xt + 24, xt + 32) (issued three tiles ago) take the slots of [xt - 8, xt), which only the scan
+        // above still needed; then the set is refilled with the columns three tiles further on
+        store_cols(xt + 24, regs[K]);
+        load_cols(xt + 48, regs[K]);
         __syncthreads();
+    };
+    for (int xt = 0; xt < W; xt += 3 * RS_TW) {
+        tile(std::integral_constant<int, 0>{}, xt);
+        if (xt + RS_TW < W) tile(std::integral_constant<int, 1>{}, xt + RS_TW);
+        if (xt + 2 * RS_TW < W) tile(std::integral_constant<int, 2>{}, xt + 2 * RS_TW);
     }
 }
 
@@ -1111,7 +1122,7 @@ int launch_iterate_q_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const fl
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
     hipLaunchKernelGGL((k_iterate_q<MH, false, 256, true>), grid, dim3(768), G::SMEM, ctx->stream, R0, R1, pair_stride,
                        flow_in, flow_out, W, H, winsize, nullptr, 0, vsum);
-    hipLaunchKernelGGL(k_rowscan_solve, dim3((H + RS_ROWS - 1) / RS_ROWS, 1, n_pairs), dim3(320), RS_SMEM, ctx->stream,
+    hipLaunchKernelGGL(k_rowscan_solve, dim3((H + RS_ROWS - 1) / RS_ROWS, 1, n_pairs), dim3(RS_THREADS), RS_SMEM, ctx->stream,
                        (const double*)vsum, W, H, MH, winsize, flow_out, (size_t)W, nullptr, 0);
     return NSOF_OK;
 }
@@ -1126,7 +1137,7 @@ int launch_iterate_q_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_item* 
     dim3 grid((max_w + G::SW - 1) / G::SW, 1, n_items);
     hipLaunchKernelGGL((k_iterate_q<MH, true, 256, true>), grid, dim3(768), G::SMEM, ctx->stream, R, R, (size_t)0, flow_in,
                        flow_out, 0, 0, winsize, items, 0, vsum);
-    hipLaunchKernelGGL(k_rowscan_solve, dim3((max_h + RS_ROWS - 1) / RS_ROWS, 1, n_items), dim3(320), RS_SMEM, ctx->stream,
+    hipLaunchKernelGGL(k_rowscan_solve, dim3((max_h + RS_ROWS - 1) / RS_ROWS, 1, n_items), dim3(RS_THREADS), RS_SMEM, ctx->stream,
                        (const double*)vsum, 0, 0, MH, winsize, flow_out, (size_t)0, items, final ? 1 : 0);
     return NSOF_OK;
 }

@@ -6,6 +6,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 #include <sys/syscall.h>
@@ -696,4 +697,69 @@ extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t p
             memcpy((char*)flow + (ptrdiff_t)y * flow_stride, hF + (size_t)y * width * 2, (size_t)width * 8);
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NSOF_OK;
+}
+
+// ---- ROI gating (host arithmetic on maps of at most a few hundred cells) -------------------------------------------
+extern "C" int nsof_roi_from_surface(const double* current, int rows, int cols, int frame_w, int frame_h, int memsize,
+                                     int thres, int extend_left, int extend_right, int extend_upper, int extend_lower,
+                                     int connectivity, int flag, int* rects, int max_rects)
+{
+    if (!current || rows < 1 || cols < 1 || frame_w < 1 || frame_h < 1 || memsize < 1 || (connectivity != 4 && connectivity != 8) ||
+        (flag != 1 && flag != 2) || max_rects < 0 || (max_rects > 0 && !rects))
+        return NSOF_EINVAL;
+    const int th = frame_h / memsize, tw = frame_w / memsize;   // the transition picture: int(h / MS) x int(w / MS)
+    if (rows > th || cols > tw) return NSOF_ESHAPE;             // the reference's numba loop would write out of bounds
+    std::vector<int> lab((size_t)th * tw, 0);
+    std::vector<unsigned char> on((size_t)th * tw, 0);
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            double g = -3366.0 / std::log10(current[(size_t)y * cols + x]) - 306.0;
+            g = g < 0.0 ? 0.0 : (g > 255.0 ? 255.0 : g);        // NaN (I <= 0) compares false twice and casts to 0
+            const int gi = (g == g) ? (int)(unsigned char)g : 0;
+            on[(size_t)y * tw + x] = gi >= thres;
+        }
+    struct Box { int x0, y0, x1, y1; };
+    std::vector<Box> boxes;
+    std::vector<int> stack;
+    for (int y = 0; y < th; y++)
+        for (int x = 0; x < tw; x++) {
+            if (!on[(size_t)y * tw + x] || lab[(size_t)y * tw + x]) continue;
+            boxes.push_back({x, y, x, y});
+            const int id = (int)boxes.size();
+            lab[(size_t)y * tw + x] = id;
+            stack.assign(1, y * tw + x);
+            while (!stack.empty()) {
+                const int p = stack.back();
+                stack.pop_back();
+                const int py = p / tw, px = p % tw;
+                Box& b = boxes[id - 1];
+                b.x0 = px < b.x0 ? px : b.x0; b.x1 = px > b.x1 ? px : b.x1;
+                b.y0 = py < b.y0 ? py : b.y0; b.y1 = py > b.y1 ? py : b.y1;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if ((!dx && !dy) || (connectivity == 4 && dx && dy)) continue;
+                        const int ny = py + dy, nx = px + dx;
+                        if (ny < 0 || ny >= th || nx < 0 || nx >= tw) continue;
+                        const size_t q = (size_t)ny * tw + nx;
+                        if (on[q] && !lab[q]) { lab[q] = id; stack.push_back((int)q); }
+                    }
+            }
+        }
+    if (boxes.empty()) return 0;
+    if (flag == 2) {   // union box of all components
+        Box u = boxes[0];
+        for (const Box& b : boxes) {
+            u.x0 = b.x0 < u.x0 ? b.x0 : u.x0; u.y0 = b.y0 < u.y0 ? b.y0 : u.y0;
+            u.x1 = b.x1 > u.x1 ? b.x1 : u.x1; u.y1 = b.y1 > u.y1 ? b.y1 : u.y1;
+        }
+        boxes.assign(1, u);
+    }
+    int n = 0;
+    for (const Box& b : boxes) {
+        const int x0 = std::max(b.x0 * memsize - extend_left, 0), y0 = std::max(b.y0 * memsize - extend_upper, 0);
+        const int x1 = std::min((b.x1 + 1) * memsize + extend_right, frame_w), y1 = std::min((b.y1 + 1) * memsize + extend_lower, frame_h);
+        if (n < max_rects) { rects[4 * n] = x0; rects[4 * n + 1] = y0; rects[4 * n + 2] = x1; rects[4 * n + 3] = y1; }
+        n++;
+    }
+    return n;
 }

@@ -239,3 +239,27 @@ def opticalFlow3D(memimg1, memimg2, rgbimg1, rgbimg2, pixel_width, pixel_height,
         out = process_merged_region(stats, rgbimg1, rgbimg2, flow, pixel_width, pixel_height, cfg, flow_fn)
     cfg.mem_opticalflow_times.append(time.time() - t0)
     return out
+
+
+def roi_from_surface(current, frame_hw, cfg):
+    """ROI rectangles ``[(x0, y0, x1, y1), ...]`` of one gating slice through the C ABI (``nsof_roi_from_surface``):
+    ``current`` = a slice of the ``constructed3DMatrix`` stack (ampere).  Same arithmetic as ``opticalFlow3D`` up to
+    the crop (optical_flow_seg.py:211-252): current -> gray, threshold, connected components, per-component boxes
+    (FLAG 1) or their union (FLAG 2), scaled by MEMSIZE and extended.  Needs no GPU."""
+    import ctypes as C
+
+    from . import _lib
+    cur = np.ascontiguousarray(current, np.float64)
+    h, w = frame_hw
+    lib = _lib.load()
+    cap = 64
+    while True:
+        rects = (C.c_int * (4 * cap))()
+        n = lib.nsof_roi_from_surface(cur.ctypes.data, cur.shape[0], cur.shape[1], int(w), int(h), cfg.MEMSIZE, cfg.THRES,
+                                      cfg.EXTEND_WIDTH_LEFT, cfg.EXTEND_WIDTH_RIGHT, cfg.EXTEND_HEIGHT_UPPER,
+                                      cfg.EXTEND_HEIGHT_LOWER, cfg.CONNECT, cfg.FLAG, rects, cap)
+        if n < 0:
+            raise ValueError(f"nsof_roi_from_surface failed ({n})")
+        if n <= cap:
+            return [tuple(rects[4 * i:4 * i + 4]) for i in range(n)]
+        cap = n

@@ -79,6 +79,25 @@ def test_full_workload_counts(nsof_lib, stacks):
     assert n_roi > 200
 
 
+def test_roi_from_surface_c_abi_matches_python_gating(nsof_lib, stacks):
+    """nsof_roi_from_surface (the C export SURVEY 8b suggests) against the Python mirror of opticalFlow3D's gating on
+    EVERY slice of the reference's five constructed_3D_matrix.mat stacks, both FLAG settings, connectivity 4 and 8."""
+    from nsof import gating
+    from nsof import workload as wl
+    n = 0
+    for name, (h, w, _) in wl.DATASET_FRAMES.items():
+        for flag in (1, 2):
+            for conn in (4, 8):
+                cfg = gating.dataset_config(name, FLAG=flag, CONNECT=conn)
+                for k in range(stacks[name].shape[2]):
+                    sl = stacks[name][:, :, k]
+                    want = wl.roi_rects(gating.current_to_gray(sl), (h, w), cfg)
+                    got = gating.roi_from_surface(sl, (h, w), cfg)
+                    assert [r for r in got if r[2] > r[0] and r[3] > r[1]] == want, (name, flag, conn, k)
+                    n += len(got)
+    assert n > 1000
+
+
 def _fake_pairs(pairs, params, flows):
     for (p, q), f in zip(pairs, flows):
         f[..., 0] = p.astype(np.float32) - q
