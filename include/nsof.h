@@ -60,7 +60,7 @@ int nsof_synchronize(nsof_ctx* ctx);
 /* NSOF_OPT_EXACT_ROWSUMS (default 0): 1 = the box-filter row sums are formed as the reference library forms them, one
  * running double-precision sum along each image row, instead of per pixel -- the only place where the default path
  * leaves the library's operation order.  Same numbers to ~1e-16; where the 2x2 system is rank deficient (real footage,
- * small windows) that decides the flow's 4th decimal, and this mode then equals the CPU oracle bit for bit (about
+ * small windows) that decides the flow's 4th decimal, and this mode then equals a CPU restatement of the library bit for bit (about
  * half the throughput: the column sums pass through HBM between two kernels).  Environment default: NSOF_EXACT_ROWSUMS. */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);

@@ -998,7 +998,7 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
 //   load   the tile's column sums -> an LDS ring of 32 columns (64-B row segments)
 //   scan   thread <-> (row, plane): 8 steps of the running sum, kept in a register, results -> LDS
 //   solve  thread <-> pixel of the 64 x 8 tile: the 2x2 solve, flow stored as 64-B row segments
-// The next tile's loads are in flight during the solve.  Same arithmetic as oracle/farneback_ref.c, bit for bit.
+// The next tile's loads are in flight during the solve.  Same arithmetic and order as the library's FarnebackUpdateFlow_Blur, bit for bit.
 // ---------------------------------------------------------------------------------------------
 #ifndef NSOF_RS_ROWS
 #define NSOF_RS_ROWS 32
