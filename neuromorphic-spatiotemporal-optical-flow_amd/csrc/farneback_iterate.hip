@@ -758,8 +758,13 @@ struct QGeom {
     static constexpr int COLS = COLS_, RB = 4;
     static constexpr int RL = 2 * MH + 1 + 2 * RB;
     static constexpr int SW = (COLS - 2 * MH) & ~3;         // a solve thread owns 4 whole pixels
-    static constexpr size_t SV_BYTES = sizeof(double) * RB * 5 * COLS;
+    // Column sums of one (row, plane): the solve threads read 4 adjacent columns each, i.e. lanes 4 doubles apart -- a
+    // 4-way bank conflict on a plain row (PMC: 32 % of the kernel's LDS cycles).  Stored as four sub-rows by
+    // (column mod 4), 72 doubles apart: a lane's reads and the column-sum writes are both conflict free.
+    static constexpr int SVSUB = COLS / 4 + 8, SVW = 3 * SVSUB + COLS / 4;
+    static constexpr size_t SV_BYTES = sizeof(double) * RB * 5 * SVW;
     static constexpr size_t SMEM = SV_BYTES + sizeof(float) * RL * 5 * COLS;
+    __host__ __device__ static constexpr int svi(int col) { return (col & 3) * SVSUB + (col >> 2); }
 };
 
 template <int MH, int COLS, int GP, int TS, int RR>
@@ -820,13 +825,14 @@ __device__ __forceinline__ void q_producer_loop(float (*mring)[5][COLS], const P
 // VOUT: instead of forming the row sums and solving, the column sums of the strip's own columns go to HBM
 // (Vout: [H][5][W] doubles of this pair) -- phase A of the exact-order path, see k_rowscan_solve below.
 template <int MH, int COLS, bool VOUT = false>
-__device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double (*sv)[5][COLS], const Planes& R0,
+__device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* sv_raw, const Planes& R0,
                                                 const Planes& R1, const FlowSrc<false>& F, float2* Fout, size_t fpitch,
                                                 int W, int H, int x0, int xc, int col, int nsteps, double scale,
                                                 double* Vout = nullptr)
 {
     using G = QGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, TPR = COLS / 4;   // TPR solve threads per row
+    double (*sv)[5][G::SVW] = reinterpret_cast<double (*)[5][G::SVW]>(sv_raw);   // [4 rows][5 planes]
     double vs[5];
     {
         // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
@@ -871,7 +877,7 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double 
                     if (own && 4 * t + q < H)
                         __builtin_nontemporal_store(vs[c], Vout + ((size_t)(4 * t + q) * 5 + c) * W + (x0 + col - MH));
                 } else {
-                    sv[q][c][col] = vs[c];
+                    sv[q][c][G::svi(col)] = vs[c];
                 }
             }
             slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
@@ -884,7 +890,8 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double 
         }
         const int yo = 4 * t + hrow, xo = x0 + 4 * t4;
         if (4 * t4 < SW && yo < H && xo < W) {
-            const double (*svr)[COLS] = sv[hrow];
+            const double (*svr)[G::SVW] = sv[hrow];
+            auto at = [&](int c, int j) { return svr[c][(j & 3) * G::SVSUB + t4 + (j >> 2)]; };   // column 4 t4 + j
             double g[5];
             float2 o[4];
 #pragma unroll
@@ -894,12 +901,12 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], double 
                     for (int c = 0; c < 5; c++) {
                         double a = 0;
 #pragma unroll
-                        for (int j = 0; j <= 2 * MH; j++) a += svr[c][4 * t4 + j];
+                        for (int j = 0; j <= 2 * MH; j++) a += at(c, j);
                         g[c] = a;
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 5; c++) g[c] += svr[c][4 * t4 + p + 2 * MH] - svr[c][4 * t4 + p - 1];
+                    for (int c = 0; c < 5; c++) g[c] += at(c, p + 2 * MH) - at(c, p - 1);
                 }
                 const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
                 const double h1 = g[3] * scale, h2 = g[4] * scale;
@@ -931,7 +938,7 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
     using G = QGeom<MH, COLS>;
     constexpr int SW = G::SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
-    double (*sv)[5][COLS] = reinterpret_cast<double (*)[5][COLS]>(smem_q);                      // [4 rows]
+    void* sv = smem_q;                                                                          // [4 rows][5][SVW] doubles
     float (*mring)[5][COLS] = reinterpret_cast<float (*)[5][COLS]>(smem_q + G::SV_BYTES);       // [RL]
     const int tid = threadIdx.x, col = tid % COLS;
     const int role = __builtin_amdgcn_readfirstlane(tid / COLS);   // wave-uniform: 0 consumers, 1/2 producers A/B
