@@ -760,8 +760,9 @@ struct QGeom {
     static constexpr int SW = (COLS - 2 * MH) & ~3;         // a solve thread owns 4 whole pixels
     // Column sums of one (row, plane): the solve threads read 4 adjacent columns each, i.e. lanes 4 doubles apart -- a
     // 4-way bank conflict on a plain row (PMC: 32 % of the kernel's LDS cycles).  Stored as four sub-rows by
-    // (column mod 4), 72 doubles apart: a lane's reads and the column-sum writes are both conflict free.
-    static constexpr int SVSUB = COLS / 4 + 8, SVW = 3 * SVSUB + COLS / 4;
+    // (column mod 4), 68 doubles apart: a lane's reads (consecutive lanes, consecutive doubles) and the column-sum
+    // writes (ds_write_b64: 16 lanes per LDS cycle over 32 banks; 136 dwords = 8 mod 32) are both conflict free.
+    static constexpr int SVSUB = COLS / 4 + 4, SVW = 3 * SVSUB + COLS / 4;
     static constexpr size_t SV_BYTES = sizeof(double) * RB * 5 * SVW;
     static constexpr size_t SMEM = SV_BYTES + sizeof(float) * RL * 5 * COLS;
     __host__ __device__ static constexpr int svi(int col) { return (col & 3) * SVSUB + (col >> 2); }
