@@ -17,6 +17,7 @@
 //    rounded one in all but ~1e-9 of cases (the reference's NumPy uses SIMD pow/exp that are
 //    themselves 1-4 ulp off libm; tolerances are stated in tests/test_accum_*.py).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -257,6 +258,96 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
     }
 }
 
+// ---- scheme 2 as ONE graph launch per group of slices ---------------------------------------------------------------
+// The refractory rule makes every slice's scatter depend on the previous slice's, so a group of 32 slices is 32 (split
+// mode: 64) tiny dependent launches + the fused update -- launch overhead, not work, bounds scheme 2.  The same chain
+// captured once in a HIP graph and replayed per group: the kernels take everything that changes from group to group
+// (event range, first / last timestamp of each slice, the group's slice count) from device tables, indexed by a device
+// counter that the graph's last node advances.
+struct SliceRec {
+    long long lo, n, t_first, t_next;   // event range (relative to the staged stream) and the refractory timestamps
+};
+struct GroupRec {
+    int first, g;                       // first staged slice of the group, number of slices (<= 32)
+};
+
+__global__ __launch_bounds__(256) void k_scatter_v2_tab(const short* __restrict__ x, const short* __restrict__ y,
+                                                         const signed char* __restrict__ p,
+                                                         const SliceRec* __restrict__ slices,
+                                                         const GroupRec* __restrict__ groups, const int* __restrict__ gi,
+                                                         int s, int pol_sel, int W, long long* next_ok, unsigned* mask,
+                                                         unsigned* list, unsigned* count)
+{
+    const GroupRec gr = groups[*gi];
+    if (s >= gr.g) return;
+    const SliceRec sl = slices[gr.first + s];
+    const unsigned bit = 1u << s;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < sl.n; i += (long long)gridDim.x * 256) {
+        const long long e = sl.lo + i;
+        if (pol_sel >= 0 && (int)p[e] != pol_sel) continue;
+        const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
+        const long long ok = __hip_atomic_load(&next_ok[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ok <= sl.t_first) {
+            __hip_atomic_store(&next_ok[pix], sl.t_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mark(mask, list, count, pix, bit);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_update_sparse_tab(float* __restrict__ w, unsigned* __restrict__ mask,
+                                                            const unsigned* __restrict__ list,
+                                                            const unsigned* __restrict__ count,
+                                                            const GroupRec* __restrict__ groups, const int* __restrict__ gi,
+                                                            float v_act)
+{
+    const int n_sl = groups[*gi].g;
+    const unsigned n = *count;
+    const Drive da = drive_of(v_act);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned pix = list[i];
+        unsigned m = mask[pix];
+        mask[pix] = 0;
+        float ww = w[pix];
+        for (int s = 0; s < n_sl; s++, m >>= 1)
+            if (m & 1u) ww = update_drive(ww, da);
+        w[pix] = ww;
+    }
+}
+
+template <bool SIL_NOOP>
+__global__ __launch_bounds__(256) void k_update_dense_tab(float* __restrict__ w, unsigned* __restrict__ mask, size_t n,
+                                                           const GroupRec* __restrict__ groups, const int* __restrict__ gi,
+                                                           float v_act, float v_sil)
+{
+    const int n_sl = groups[*gi].g;
+    const Drive da = drive_of(v_act), ds = drive_of(v_sil);
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
+        unsigned m = mask[j];
+        if (m) mask[j] = 0;
+        float ww = w[j];
+        if (SIL_NOOP) {
+            for (; m; m &= m - 1) ww = update_drive(ww, da);
+        } else {
+            for (int s = 0; s < n_sl; s++) {
+                const bool act = (m >> s) & 1u;
+                Drive d;
+                d.ka = act ? da.ka : ds.ka;
+                d.s = act ? da.s : ds.s;
+                d.b = act ? da.b : ds.b;
+                ww = update_drive(ww, d);
+            }
+        }
+        w[j] = ww;
+    }
+}
+
+__global__ void k_group_done(int* gi, unsigned* count)
+{
+    *gi += 1;
+    count[0] = 0;
+    count[1] = 0;
+}
+
 // Frame-driven variant (/root/reference/simulation/simulationcode_v4_transistor_uav.m:146-227, 332-347), float64:
 // drive voltage from the absolute difference of two compressed frames, then n_sub Euler sub-steps of the same ODE.
 __device__ __forceinline__ double frame_update(double w, double V, double dt)
@@ -347,6 +438,15 @@ struct nsof_accum {
     // staged stream (nsof_accum_set_events / the staging half of nsof_accum_step_events): slice bounds relative to
     // the first staged event, and for scheme 2 the first / last+refractory timestamp of every slice
     std::vector<long long> h_rel, h_tfirst, h_tnext;
+    // scheme 2 graph replay: per-slice / per-group tables on the device, the group counter, the captured graph
+    SliceRec* d_slices = nullptr;
+    size_t slices_cap = 0;
+    GroupRec* d_groups = nullptr;
+    size_t groups_cap = 0;
+    int* d_gi = nullptr;
+    hipGraphExec_t graph = nullptr;
+    bool graph_dense = false, graph_sparse_ok = false;
+    int use_graph = -1;   // -1: from the environment (NSOF_ACCUM_GRAPH, default on), 0 / 1: forced
 };
 
 static int accum_alloc(nsof_ctx* ctx, void** p, size_t bytes)
@@ -368,6 +468,8 @@ extern "C" void nsof_accum_destroy(nsof_accum* a)
         hipFree(a->w[i]); hipFree(a->next_ok[i]); hipFree(a->mask[i]); hipFree(a->list[i]); hipFree(a->snap[i]);
     }
     hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
+    hipFree(a->d_slices); hipFree(a->d_groups); hipFree(a->d_gi);
+    if (a->graph) hipGraphExecDestroy(a->graph);
     delete a;
 }
 
@@ -485,6 +587,7 @@ static int accum_stage(nsof_accum* a, const int16_t* x, const int16_t* y, const 
         for (int i = 0; i < narr; i++)
             if ((rc = accum_alloc(ctx, (void**)&a->list[i], cap * sizeof(unsigned)))) return rc;
         a->ev_cap = cap;
+        if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }   // captured pointers are stale
     }
     if ((size_t)(n_slices + 1) > a->bounds_cap) {
         NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -508,7 +611,22 @@ static int accum_stage(nsof_accum* a, const int16_t* x, const int16_t* y, const 
                 a->h_tnext[s] = t[sb[s + 1] - 1] + REFRACTORY_US;
             }
     NSOF_HIP(ctx, hipMemcpyAsync(a->dbounds, a->h_rel.data(), a->h_rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays are not retained
+    std::vector<SliceRec> recs;
+    if (a->scheme == 2 && n_slices > 0) {   // per-slice table of the graph replay
+        recs.resize((size_t)n_slices);
+        for (int64_t s = 0; s < n_slices; s++)
+            recs[s] = SliceRec{a->h_rel[s], a->h_rel[s + 1] - a->h_rel[s], a->h_tfirst[s], a->h_tnext[s]};
+        if ((size_t)n_slices > a->slices_cap) {
+            NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(a->d_slices);
+            a->d_slices = nullptr;
+            if ((rc = accum_alloc(ctx, (void**)&a->d_slices, (size_t)n_slices * sizeof(SliceRec)))) return rc;
+            a->slices_cap = (size_t)n_slices;
+            if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }   // captured pointers are stale
+        }
+        NSOF_HIP(ctx, hipMemcpyAsync(a->d_slices, recs.data(), recs.size() * sizeof(SliceRec), hipMemcpyHostToDevice, ctx->stream));
+    }
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's arrays (and recs) are not retained
     return NSOF_OK;
 }
 
@@ -529,6 +647,88 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
 
     int64_t s0 = s_begin;
     const int64_t s_end = s_begin + n_slices;
+    if (a->use_graph < 0) {
+        const char* e = getenv("NSOF_ACCUM_GRAPH");
+        a->use_graph = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (a->scheme == 2 && a->use_graph && n_slices > 0) {
+        // groups of this call (same rule as below: up to 32 slices, ending right after a snapshot slice)
+        std::vector<GroupRec> groups;
+        std::vector<char> snap_after;
+        {
+            int64_t c = a->slice_counter, q = s_begin;
+            while (q < s_end) {
+                int64_t g = s_end - q < MAX_GROUP ? s_end - q : MAX_GROUP;
+                if (snap_every > 0) {
+                    const int64_t to_snap = (c % snap_every == 0) ? 1 : (snap_every - c % snap_every) + 1;
+                    if (to_snap < g) g = to_snap;
+                }
+                groups.push_back(GroupRec{(int)q, (int)g});
+                c += g;
+                q += g;
+                snap_after.push_back(snap_every > 0 && (c - 1) % snap_every == 0);
+            }
+        }
+        if (groups.size() > a->groups_cap) {
+            NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(a->d_groups);
+            a->d_groups = nullptr;
+            const size_t cap = groups.size() + groups.size() / 2 + 16;
+            if ((rc = accum_alloc(ctx, (void**)&a->d_groups, cap * sizeof(GroupRec)))) return rc;
+            a->groups_cap = cap;
+            if (a->graph) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }
+        }
+        if (!a->d_gi && (rc = accum_alloc(ctx, (void**)&a->d_gi, sizeof(int)))) return rc;
+        NSOF_HIP(ctx, hipMemcpyAsync(a->d_groups, groups.data(), groups.size() * sizeof(GroupRec), hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipMemsetAsync(a->d_gi, 0, sizeof(int), ctx->stream));
+        NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 2 * sizeof(unsigned), ctx->stream));
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `groups` is a stack-lifetime buffer
+        if (a->graph && (a->graph_dense != !sparse)) { hipGraphExecDestroy(a->graph); a->graph = nullptr; }
+        if (!a->graph) {
+            hipGraph_t gr = nullptr;
+            NSOF_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            const dim3 sg(16), blk(256);
+            for (int s = 0; s < MAX_GROUP; s++) {
+                if (a->split) {
+                    hipLaunchKernelGGL(k_scatter_v2_tab, sg, blk, 0, ctx->stream, a->dx, a->dy, a->dp, a->d_slices, a->d_groups,
+                                       a->d_gi, s, 1, a->W, a->next_ok[0], a->mask[0], a->list[0], a->count);
+                    hipLaunchKernelGGL(k_scatter_v2_tab, sg, blk, 0, ctx->stream, a->dx, a->dy, a->dp, a->d_slices, a->d_groups,
+                                       a->d_gi, s, 0, a->W, a->next_ok[1], a->mask[1], a->list[1], a->count + 1);
+                } else {
+                    hipLaunchKernelGGL(k_scatter_v2_tab, sg, blk, 0, ctx->stream, a->dx, a->dy, a->dp, a->d_slices, a->d_groups,
+                                       a->d_gi, s, -1, a->W, a->next_ok[0], a->mask[0], a->list[0], a->count);
+                }
+            }
+            for (int i = 0; i < narr; i++) {
+                if (sparse)
+                    hipLaunchKernelGGL(k_update_sparse_tab, dim3(64), blk, 0, ctx->stream, a->w[i], a->mask[i], a->list[i],
+                                       a->count + i, a->d_groups, a->d_gi, v_act);
+                else if (dead_zone)
+                    hipLaunchKernelGGL(k_update_dense_tab<true>, dim3(grid_for(a->npx, 8192)), blk, 0, ctx->stream, a->w[i],
+                                       a->mask[i], a->npx, a->d_groups, a->d_gi, v_act, a->silent_v);
+                else
+                    hipLaunchKernelGGL(k_update_dense_tab<false>, dim3(grid_for(a->npx, 8192)), blk, 0, ctx->stream, a->w[i],
+                                       a->mask[i], a->npx, a->d_groups, a->d_gi, v_act, a->silent_v);
+            }
+            hipLaunchKernelGGL(k_group_done, dim3(1), dim3(1), 0, ctx->stream, a->d_gi, a->count);
+            hipError_t e1 = hipStreamEndCapture(ctx->stream, &gr);
+            if (e1 != hipSuccess) return nsof_set_error(ctx, NSOF_EDEVICE, "graph capture failed: %s", hipGetErrorString(e1));
+            hipError_t e2 = hipGraphInstantiate(&a->graph, gr, nullptr, nullptr, 0);
+            hipGraphDestroy(gr);
+            if (e2 != hipSuccess) { a->graph = nullptr; return nsof_set_error(ctx, NSOF_EDEVICE, "graph instantiate failed: %s", hipGetErrorString(e2)); }
+            a->graph_dense = !sparse;
+        }
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            {
+                nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+                NSOF_HIP(ctx, hipGraphLaunch(a->graph, ctx->stream));
+            }
+            a->slice_counter += groups[gi].g;
+            if (snap_after[gi])
+                if ((rc = accum_snapshot(a))) return rc;
+        }
+        return NSOF_OK;
+    }
     while (s0 < s_end) {
         // group = up to 32 slices, ending right after the next snapshot slice
         int64_t g = s_end - s0 < MAX_GROUP ? s_end - s0 : MAX_GROUP;
