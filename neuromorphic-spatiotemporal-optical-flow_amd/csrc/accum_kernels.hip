@@ -260,8 +260,9 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
 
 // ---- scheme 2 as ONE graph launch per group of slices ---------------------------------------------------------------
 // The refractory rule makes every slice's scatter depend on the previous slice's, so a group of 32 slices is 32 (split
-// mode: 64) tiny dependent launches + the fused update -- launch overhead, not work, bounds scheme 2.  The same chain
-// captured once in a HIP graph and replayed per group: the kernels take everything that changes from group to group
+// mode: 64) tiny dependent launches + the fused update -- launch overhead, not work, bounds scheme 2.  Here the same
+// chain is captured once in a HIP graph and replayed per group (opt-in, NSOF_ACCUM_GRAPH=1: measured slower, see
+// accum_advance): the kernels take everything that changes from group to group
 // (event range, first / last timestamp of each slice, the group's slice count) from device tables, indexed by a device
 // counter that the graph's last node advances.
 struct SliceRec {
@@ -446,7 +447,7 @@ struct nsof_accum {
     int* d_gi = nullptr;
     hipGraphExec_t graph = nullptr;
     bool graph_dense = false, graph_sparse_ok = false;
-    int use_graph = -1;   // -1: from the environment (NSOF_ACCUM_GRAPH, default on), 0 / 1: forced
+    int use_graph = -1;   // -1: from the environment (NSOF_ACCUM_GRAPH=1 switches it on), 0 / 1: forced
 };
 
 static int accum_alloc(nsof_ctx* ctx, void** p, size_t bytes)
@@ -648,8 +649,11 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
     int64_t s0 = s_begin;
     const int64_t s_end = s_begin + n_slices;
     if (a->use_graph < 0) {
+        // measured (scripts/bench_accum_v2.py, 3840x2160, 1 M events/s): the replayed graph is 7-12 % SLOWER than the
+        // plain launches (split 130 k vs 140 k slices/s, magnitude 224 k vs 255 k) -- a graph node costs as much as a
+        // stream launch here -- so it is opt-in
         const char* e = getenv("NSOF_ACCUM_GRAPH");
-        a->use_graph = (e && e[0] == '0') ? 0 : 1;
+        a->use_graph = (e && e[0] == '1') ? 1 : 0;
     }
     if (a->scheme == 2 && a->use_graph && n_slices > 0) {
         // groups of this call (same rule as below: up to 32 slices, ending right after a snapshot slice)
