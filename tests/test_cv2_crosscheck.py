@@ -54,3 +54,15 @@ def test_hip_vs_cv2(nsof_lib, ctx, kw):
     finally:
         nsof.uninstall(cv2)
     assert cv2.calcOpticalFlowFarneback is saved
+
+
+def test_connected_components_label_order_vs_cv2(nsof_lib):
+    """Label ORDER of the gating's connected components against cv2 itself (FLAG 1 pastes overlapping component boxes in
+    label order, optical_flow_seg.py:129-164)."""
+    rng = np.random.default_rng(0)
+    for shape in [(4, 4), (24, 13), (15, 15), (16, 16)]:
+        for p in (0.2, 0.5, 0.8):
+            img = (rng.random(shape) < p).astype(np.uint8) * 255
+            n, labels, stats, _ = nsof_lib.connectedComponentsWithStats(img, connectivity=4)
+            n2, labels2, stats2, _ = cv2.connectedComponentsWithStats(img, connectivity=4)
+            assert n == n2 and np.array_equal(labels, labels2) and np.array_equal(stats, stats2)

@@ -31,6 +31,13 @@ def test_current_to_gray(nsof_lib):
 
 
 def test_connected_components_match_scipy(nsof_lib):
+    """Partition, statistics AND label order against scipy.ndimage.label (raster order of each component's first
+    pixel).  PARITY UNPINNED vs cv2 for the label ORDER: cv2.connectedComponentsWithStats numbers its components in
+    the order its two-pass algorithm (SAUF / Spaghetti, depending on the build) resolves them, which for 4-connectivity
+    is the raster order of the first pixel in every case checked by hand but is not documented.  The order only matters
+    for FLAG 1 datasets when component boxes overlap (the later paste wins, optical_flow_seg.py:162); the union box
+    of FLAG 2 and every non-overlapping case do not depend on it.  cv2 is not installable here; the live cross-check
+    lives in tests/test_cv2_crosscheck.py."""
     from scipy import ndimage
     rng = np.random.default_rng(0)
     for shape in [(4, 4), (24, 13), (15, 15), (16, 16), (7, 31)]:
