@@ -76,6 +76,7 @@ extern "C" int nsof_prof_collect(nsof_ctx* ctx, int id, double* total_ms, long l
 {
     if (!ctx || id < 0 || id >= NSOF_K_COUNT) return NSOF_EINVAL;
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side) NSOF_HIP(ctx, hipStreamSynchronize(ctx->side));
     nsof_prof_slot& s = ctx->prof[id];
     for (size_t i = 0; i < s.used; i++) {
         float ms = 0;
@@ -207,6 +208,8 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     for (auto ev : ctx->het_ev)
         if (ev) hipEventDestroy(ev);
     nsof_pipe_destroy(ctx);
+    for (auto ev : ctx->ov_events) hipEventDestroy(ev);
+    if (ctx->side) hipStreamDestroy(ctx->side);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -543,7 +546,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
     const size_t szV = exact ? align_up(B * 5 * n0 * 8, 256) : 0;   // transposed column sums of the exact order
     if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM + szV))) return rc;
-    char* base = (char*)ctx->ws;
+    char* base = (char*)ctx->ws;   // (re-derived below if the level overlap grows the workspace)
     float* dI = (float*)base;
     float* dR = (float*)(base + szI);
     float* dS = (float*)(base + szI + szR);
@@ -562,6 +565,89 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
                           nsof_iterate_upsample_supported(winsize, width, height);
     const int flips = fused ? (fold_ups ? (L + 1) * iterations : L * (1 + iterations) + iterations) : L;
     int cur = flips & 1;
+
+    // ---- level overlap (default for the plain uniform batch; NSOF_OVERLAP=0 switches it off) -------------------------
+    // The iteration and expansion kernels hold a CU through its LDS (159 / 41 KB per workgroup) while leaving VALU and
+    // HBM slots idle; the pyramid-level and flow-resample kernels use no LDS and few registers.  On a side stream,
+    // the pyramid level of level k-1 runs next to the iterations of level k and the flow resample for level k-1 next
+    // to its polynomial expansion; events order the hand-overs.  Same kernels, same arguments, same results.
+    static const bool overlap_env = [] { const char* e = getenv("NSOF_OVERLAP"); return !(e && e[0] == '0'); }();
+    if (fused && !exact && !fold_ups && overlap_env && L >= 1 && iterations > 0) {
+        if (!ctx->side) NSOF_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        while (ctx->ov_events.size() < (size_t)4 * (L + 1)) {
+            hipEvent_t ev;
+            NSOF_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->ov_events.push_back(ev);
+        }
+        auto EV = [&](int k, int which) { return ctx->ov_events[(size_t)4 * k + which]; };   // 0 prep, 1 poly, 2 iter, 3 ups
+        struct StreamSwap {
+            nsof_ctx* c; hipStream_t saved;
+            StreamSwap(nsof_ctx* cc, hipStream_t s) : c(cc), saved(cc->stream) { c->stream = s; }
+            ~StreamSwap() { c->stream = saved; }
+        };
+        // second level-image buffer behind the regular workspace
+        const size_t base_bytes = szI + szR + szS + szM + szV;
+        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, base_bytes + szI))) return rc;
+        base = (char*)ctx->ws;
+        dI = (float*)base;
+        dR = (float*)(base + szI);
+        dS = (float*)(base + szI + szR);
+        fb[1] = dS;
+        float* Ibuf[2] = {dI, (float*)(base + base_bytes)};
+        auto prep_level = [&](int k, float* I) -> int {
+            int wk, hk, ks;
+            double sg;
+            nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, &ks, &sg);
+            nsof_blur_taps bt;
+            if (int r = nsof_host_blur_taps(ks, sg, &bt))
+                return nsof_set_error(ctx, r, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
+            const size_t nk = (size_t)wk * hk;
+            if (sequence) return nsof_launch_prep(ctx, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, bt, I);
+            for (int i = 0; i < 2; i++)
+                if (int r = nsof_launch_prep(ctx, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width, height, wk,
+                                             hk, bt, I + (size_t)i * B * nk))
+                    return r;
+            return NSOF_OK;
+        };
+        const hipStream_t mainS = ctx->stream, sideS = ctx->side;
+        if ((rc = prep_level(L, Ibuf[L & 1]))) return rc;
+        for (int k = L; k >= 0; k--) {
+            int wk, hk;
+            nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, nullptr, nullptr);
+            const size_t nk = (size_t)wk * hk;
+            if (k < L) NSOF_HIP(ctx, hipStreamWaitEvent(mainS, EV(k, 0), 0));          // this level's images are ready
+            if ((rc = nsof_launch_polyexp(ctx, (int)n_img, Ibuf[k & 1], wk, hk, ptaps, dR))) return rc;
+            if (k > 0) {   // next level's images: on the side stream, next to this level's iterations
+                NSOF_HIP(ctx, hipEventRecord(EV(k, 1), mainS));
+                NSOF_HIP(ctx, hipStreamWaitEvent(sideS, EV(k, 1), 0));
+                StreamSwap sw(ctx, sideS);
+                if ((rc = prep_level(k - 1, Ibuf[(k - 1) & 1]))) return rc;
+                NSOF_HIP(ctx, hipEventRecord(EV(k - 1, 0), sideS));
+            }
+            if (k == L) NSOF_HIP(ctx, hipMemsetAsync(fb[cur], 0, B * nk * 8, mainS));
+            else NSOF_HIP(ctx, hipStreamWaitEvent(mainS, EV(k, 3), 0));                // the resampled flow is ready
+            const float* R0 = dR;
+            const float* R1 = dR + (sequence ? (size_t)1 : B) * 5 * nk;
+            for (int it = 0; it < iterations; it++) {
+                if ((rc = nsof_launch_iterate(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize))) return rc;
+                cur ^= 1;
+            }
+            if (k > 0) {   // resample this level's flow for the next one: on the side stream, next to its expansion
+                int w1, h1;
+                nsof_farneback_level_size(width, height, pyr_scale, k - 1, &w1, &h1, nullptr, nullptr);
+                NSOF_HIP(ctx, hipEventRecord(EV(k, 2), mainS));
+                NSOF_HIP(ctx, hipStreamWaitEvent(sideS, EV(k, 2), 0));
+                StreamSwap sw(ctx, sideS);
+                if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, fb[cur], wk, hk, fb[cur ^ 1], w1, h1, (float)(1. / pyr_scale))))
+                    return rc;
+                cur ^= 1;
+                NSOF_HIP(ctx, hipEventRecord(EV(k - 1, 3), sideS));
+            }
+        }
+        if (fb[cur] != d_flow)
+            NSOF_HIP(ctx, hipMemcpyAsync(d_flow, fb[cur], B * n0 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return NSOF_OK;
+    }
 
     bool have_prev = false;
     int pw = 0, ph = 0;

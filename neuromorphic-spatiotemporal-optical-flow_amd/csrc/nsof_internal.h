@@ -48,6 +48,10 @@ struct nsof_ctx {
     int het_flip = 0;
     // pipelined host entry (nsof_farneback_u8_batch): copy streams, per-slot staging and events
     struct nsof_pipe* pipe = nullptr;
+    // level overlap of the uniform batch driver: a side stream for the LDS-free stages (pyramid level of the next
+    // level, flow resample) that share the CUs with the LDS-bound iteration / expansion kernels, and its events
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ov_events;
 };
 
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
