@@ -566,12 +566,15 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     const int flips = fused ? (fold_ups ? (L + 1) * iterations : L * (1 + iterations) + iterations) : L;
     int cur = flips & 1;
 
-    // ---- level overlap (default for the plain uniform batch; NSOF_OVERLAP=0 switches it off) -------------------------
-    // The iteration and expansion kernels hold a CU through its LDS (159 / 41 KB per workgroup) while leaving VALU and
-    // HBM slots idle; the pyramid-level and flow-resample kernels use no LDS and few registers.  On a side stream,
-    // the pyramid level of level k-1 runs next to the iterations of level k and the flow resample for level k-1 next
-    // to its polynomial expansion; events order the hand-overs.  Same kernels, same arguments, same results.
-    static const bool overlap_env = [] { const char* e = getenv("NSOF_OVERLAP"); return !(e && e[0] == '0'); }();
+    // ---- level overlap (opt-in experiment, NSOF_OVERLAP=1) -----------------------------------------------------------
+    // The iteration and expansion kernels hold a CU through its LDS (159 / 41 KB per workgroup) while the counters show
+    // VALU and HBM only 50-65 % busy; the pyramid-level and flow-resample kernels use no LDS and few registers.  On a
+    // side stream, the pyramid level of level k-1 runs next to the iterations of level k and the flow resample for
+    // level k-1 next to its polynomial expansion; events order the hand-overs.  Same kernels, arguments and results.
+    // Measured (256 pairs 1080p): every kernel slows down by what the others gain -- iterate 23.7 -> 26.3 ms, polyexp
+    // 8.9 -> 10.4, prep 2.9 -> 3.9, resample 1.5 -> 2.3 per step, 6877 vs 6804 pairs/s -- there is no idle capacity to
+    // harvest next to these kernels, so the single-stream order stays the default.
+    static const bool overlap_env = [] { const char* e = getenv("NSOF_OVERLAP"); return e && e[0] == '1'; }();
     if (fused && !exact && !fold_ups && overlap_env && L >= 1 && iterations > 0) {
         if (!ctx->side) NSOF_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         while (ctx->ov_events.size() < (size_t)4 * (L + 1)) {
