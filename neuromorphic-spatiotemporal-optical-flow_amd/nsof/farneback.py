@@ -50,10 +50,16 @@ def _as_gray_u8(a, name):
     return a
 
 
+_DEFAULT_EXACT = None   # install(exact=...) sets it: None = the context's setting (NSOF_EXACT_ROWSUMS), True / False = forced
+
+
 def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags,  # noqa: A002,N802
-                             *, ctx=None):
+                             *, ctx=None, exact=None):
     """Same signature and result as ``cv2.calcOpticalFlowFarneback``: float32 (H, W, 2), (u, v) interleaved,
-    such that ``next(x+u, y+v) ~ prev(x, y)``.  ``flow=None`` allocates; a matching float32 array is reused."""
+    such that ``next(x+u, y+v) ~ prev(x, y)``.  ``flow=None`` allocates; a matching float32 array is reused.
+    ``exact`` (keyword only): True = box-filter row sums in the library's own order for this call
+    (``NSOF_OPT_EXACT_ROWSUMS``: bit-identical to the CPU restatement on any input, about half the throughput),
+    False = the default per-pixel sums, None = whatever the context / ``install(exact=...)`` says."""
     prev = _as_gray_u8(prev, "prev")
     next = _as_gray_u8(next, "next")  # noqa: A001
     if prev.shape != next.shape:
@@ -67,9 +73,18 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     else:
         out = np.empty((h, w, 2), np.float32)
     ctx = ctx or default_context()
-    rc = ctx._lib.nsof_farneback_u8(ctx.ptr, prev.ctypes.data, prev.strides[0], next.ctypes.data, next.strides[0],
-                                    w, h, out.ctypes.data, out.strides[0], float(pyr_scale), int(levels),
-                                    int(winsize), int(iterations), int(poly_n), float(poly_sigma), int(flags))
+    exact = _DEFAULT_EXACT if exact is None else exact
+    saved = None
+    if exact is not None:
+        saved = ctx.get_option(_lib.OPT_EXACT_ROWSUMS)
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1 if exact else 0)
+    try:
+        rc = ctx._lib.nsof_farneback_u8(ctx.ptr, prev.ctypes.data, prev.strides[0], next.ctypes.data, next.strides[0],
+                                        w, h, out.ctypes.data, out.strides[0], float(pyr_scale), int(levels),
+                                        int(winsize), int(iterations), int(poly_n), float(poly_sigma), int(flags))
+    finally:
+        if saved is not None:
+            ctx.set_option(_lib.OPT_EXACT_ROWSUMS, saved)
     ctx.check(rc, "calcOpticalFlowFarneback")
     return out
 
@@ -278,10 +293,12 @@ def farneback_many(pairs, params, n_streams=8, pool=None):
 _saved_cv2_fn = None
 
 
-def install(cv2_module=None):
+def install(cv2_module=None, exact=None):
     """Assign ``calcOpticalFlowFarneback`` onto ``cv2`` (the reference looks the attribute up at call
-    time, so its scripts then run on the GPU unmodified).  Returns the patched module."""
-    global _saved_cv2_fn
+    time, so its scripts then run on the GPU unmodified).  Returns the patched module.  ``exact=True`` makes every
+    call through the drop-in use the library's own row-sum order (bit-faithful on any footage)."""
+    global _saved_cv2_fn, _DEFAULT_EXACT
+    _DEFAULT_EXACT = exact
     if cv2_module is None:
         import cv2 as cv2_module  # raises ImportError where cv2 is absent: nothing to patch
     if _saved_cv2_fn is None:
@@ -291,7 +308,8 @@ def install(cv2_module=None):
 
 
 def uninstall(cv2_module=None):
-    global _saved_cv2_fn
+    global _saved_cv2_fn, _DEFAULT_EXACT
+    _DEFAULT_EXACT = None
     if cv2_module is None:
         import cv2 as cv2_module
     if _saved_cv2_fn is not None:

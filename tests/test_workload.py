@@ -350,6 +350,8 @@ def test_exact_rowsum_order_equals_oracle_on_real_frames(nsof_lib, ctx, oracle, 
     finally:
         ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
     assert np.array_equal(one, refs[0])
+    assert np.array_equal(nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx, exact=True), refs[0])   # per call
+    assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 0                                                          # ... and restored
     assert np.array_equal(lst[0], refs[0]) and np.array_equal(lst[1], refs[1])
     assert np.array_equal(lst[2], oracle.farneback(np.ascontiguousarray(fr[0][100:400, 50:700]),
                                                    np.ascontiguousarray(fr[1][100:400, 50:700]), *B))
