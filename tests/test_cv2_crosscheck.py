@@ -66,3 +66,71 @@ def test_connected_components_label_order_vs_cv2(nsof_lib):
             n, labels, stats, _ = nsof_lib.connectedComponentsWithStats(img, connectivity=4)
             n2, labels2, stats2, _ = cv2.connectedComponentsWithStats(img, connectivity=4)
             assert n == n2 and np.array_equal(labels, labels2) and np.array_equal(stats, stats2)
+
+
+# ---- the pieces around the flow call: every CPU restatement / host mirror against cv2 itself -------------
+def test_gray_conversion_vs_cv2(nsof_lib):
+    """frame_to_gray == cv2.cvtColor(..., COLOR_RGB2GRAY / COLOR_BGR2GRAY) on 8-bit frames (optical_flow_seg.py:439-447)."""
+    from nsof import gating
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    assert np.array_equal(gating.frame_to_gray(f, "RGB2GRAY"), cv2.cvtColor(f, cv2.COLOR_RGB2GRAY))
+    assert np.array_equal(gating.frame_to_gray(f, "BGR2GRAY"), cv2.cvtColor(f, cv2.COLOR_BGR2GRAY))
+
+
+def test_pyramid_level_vs_cv2(oracle):
+    """Level image of the restatement == resize(GaussianBlur(float32(img))) as the library's driver forms it
+    (Appendix A of SURVEY.md): exact where the wheel's blur/resize do not take an FMA / IPP route, 1e-4 otherwise."""
+    from nsof import synth
+    img, _ = synth.make_pair(9, 270, 480)
+    for pyr_scale, k in [(0.5, 0), (0.5, 1), (0.5, 3), (0.6, 2)]:
+        wk, hk, ks, sg = oracle.level_geometry(480, 270, pyr_scale, k)
+        want = cv2.resize(cv2.GaussianBlur(img.astype(np.float32), (ks, ks), sg, sigmaY=sg), (wk, hk),
+                          interpolation=cv2.INTER_LINEAR)
+        got = oracle.pyr_level(img, pyr_scale, k)
+        assert got.shape == want.shape and float(np.abs(got - want).max()) < 1e-4
+
+
+def test_structuring_element_and_morphology_vs_cv2(oracle):
+    """getStructuringElement / dilate / erode restatements (segmentation head, optical_flow_seg.py:350-353) == cv2."""
+    rng = np.random.default_rng(5)
+    for shape, code in ((0, cv2.MORPH_RECT), (1, cv2.MORPH_CROSS), (2, cv2.MORPH_ELLIPSE)):
+        for kw, kh in [(10, 10), (3, 3), (7, 5), (4, 9)]:
+            assert np.array_equal(oracle.structuring_element(shape, kw, kh), cv2.getStructuringElement(code, (kw, kh)))
+    mask = (rng.random((120, 160)) < 0.02).astype(np.uint8) * 255
+    k = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (10, 10))
+    assert np.array_equal(oracle.morph(1, mask, k), cv2.dilate(mask, k))
+    assert np.array_equal(oracle.morph(0, cv2.dilate(mask, k), k), cv2.erode(cv2.dilate(mask, k), k))
+
+
+def test_remap_vs_cv2(oracle):
+    """8-bit bilinear remap restatement (prediction warp, optical_flow_prediction.py:293-300, 584-586) == cv2.remap,
+    replicate and constant borders, maps leaving the image."""
+    rng = np.random.default_rng(7)
+    src = rng.integers(0, 256, (90, 140), dtype=np.uint8)
+    ys, xs = np.mgrid[0:90, 0:140].astype(np.float32)
+    mx = (xs + rng.normal(0, 6, xs.shape)).astype(np.float32)
+    my = (ys + rng.normal(0, 6, ys.shape)).astype(np.float32)
+    assert np.array_equal(oracle.remap_linear(src, mx, my, border=1),
+                          cv2.remap(src, mx, my, cv2.INTER_LINEAR, borderMode=cv2.BORDER_REPLICATE))
+    assert np.array_equal(oracle.remap_linear(src, mx, my, border=0, cval=0), cv2.remap(src, mx, my, cv2.INTER_LINEAR))
+
+
+@pytest.mark.gpu
+def test_heads_hip_vs_cv2(nsof_lib, ctx):
+    """The GPU heads against cv2 directly: motion mask (threshold + 5 x dilate/erode), prediction remap."""
+    nsof = nsof_lib
+    rng = np.random.default_rng(11)
+    flow = (rng.normal(0, 1.2, (200, 300, 2))).astype(np.float32)
+    mag = np.sqrt(flow[..., 0].astype(np.float64) ** 2 + flow[..., 1].astype(np.float64) ** 2)
+    m = np.zeros((200, 300), np.uint8)
+    m[mag > 1] = 255
+    k = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (10, 10))
+    for _ in range(5):
+        m = cv2.erode(cv2.dilate(m, k), k)
+    assert np.array_equal(nsof.motion_mask(flow, 1, ctx=ctx), m)
+    src = rng.integers(0, 256, (200, 300, 3), dtype=np.uint8)
+    ys, xs = np.mgrid[0:200, 0:300].astype(np.float32)
+    mx, my = (xs + flow[..., 0]).astype(np.float32), (ys + flow[..., 1]).astype(np.float32)
+    assert np.array_equal(nsof.remap(src, mx, my, nsof.INTER_LINEAR, borderMode=nsof.BORDER_REPLICATE, ctx=ctx),
+                          cv2.remap(src, mx, my, cv2.INTER_LINEAR, borderMode=cv2.BORDER_REPLICATE))
