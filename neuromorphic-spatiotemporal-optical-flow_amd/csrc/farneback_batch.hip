@@ -76,6 +76,25 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
     for (int i = 0; i < n; i++)
         if (int rc = validate_desc(ctx, i, descs[i], p)) return rc;
 
+    // A list of equal shapes laid out at constant strides (what the pipelined host entry builds for a video) is the
+    // uniform batch: it takes that driver and its specialised kernels (decimating pyramid levels, XCD-aware placement).
+    if (n >= 2) {
+        const nsof_pair_desc& d0 = descs[0];
+        const ptrdiff_t ps = descs[1].prev - d0.prev;
+        bool uniform = d0.prev_stride == d0.next_stride && ps > 0 && d0.flow_stride == (ptrdiff_t)d0.width * 8;
+        const ptrdiff_t fs = (ptrdiff_t)d0.width * d0.height * 2;   // floats between consecutive dense flow fields
+        for (int i = 1; i < n && uniform; i++) {
+            const nsof_pair_desc& d = descs[i];
+            uniform = d.width == d0.width && d.height == d0.height && d.prev_stride == d0.prev_stride &&
+                      d.next_stride == d0.prev_stride && d.flow_stride == d0.flow_stride &&
+                      d.prev - d0.prev == (ptrdiff_t)i * ps && d.next - d0.next == (ptrdiff_t)i * ps &&
+                      d.flow - d0.flow == (ptrdiff_t)i * fs;
+        }
+        if (uniform)
+            return nsof_farneback_core(ctx, false, n, d0.prev, d0.next, d0.prev_stride, ps, d0.width, d0.height, d0.flow,
+                                       p.pyr_scale, p.levels, p.winsize, p.iterations, p.poly_n, p.poly_sigma, p.flags);
+    }
+
     // Items the work-list kernels cover: fused iteration available (window 2..15, >= 1 iteration, at least 2x2 px).
     const bool het_params = p.iterations >= 1 && p.winsize / 2 >= 1 && p.winsize / 2 <= 7;
     const bool exact = ctx->opt_exact_rowsums != 0;
