@@ -111,6 +111,8 @@ def main():
                     help="skip the joined events -> accumulator -> flow leg (BASELINE config 5) and its accumulator record")
     ap.add_argument("--no-fast-leg", action="store_true",
                     help="skip the extra leg that times the opt-in float polynomial expansion (NSOF_OPT_POLYEXP_F32)")
+    ap.add_argument("--no-param-legs", action="store_true",
+                    help="skip the extra legs that time the reference's other two parameter sets (B, C) on the same frames")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--mode", choices=["pairs", "sequence"], default="pairs",
                     help="pairs (headline): independent frame pairs; sequence: pairs+1 consecutive frames, the "
@@ -252,10 +254,16 @@ def main():
                                         prof=prof, steps=max(2, min(args.steps, 5))))
         if world == 1 and args.mode == "pairs" and not args.no_fast_leg:
             out.update(exact_mode_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, h, w))
+        if world == 1 and prof and args.mode == "pairs" and args.params == "A" and not args.no_param_legs:
+            for name, q in (("B", PARAMS_B), ("C", PARAMS_C)):
+                out["params_" + name] = params_leg(nsof, _lib, ctx, torch, q, prevs, nexts, flow, min(n, 128), h, w,
+                                                   kernel_ids)
         if world == 1 and not args.no_config5 and args.mode == "pairs":
             out.update(config5_leg(nsof, torch, local_rank))
         if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
             out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
+        if world == 1 and args.mode == "pairs" and not args.no_param_legs:
+            out["single_call"] = single_call_leg(nsof, _lib, ctx, torch, p, prevs, nexts, h, w)
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
             exact_check(out, nsof, p, prevs, nexts)
@@ -302,6 +310,87 @@ def fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg
         "option": "NSOF_OPT_POLYEXP_F32=1 (opt-in; default path is the exact one)", "value": round(n * steps / dt, 2),
         "unit": "pairs/s", "max_abs_epe_vs_exact_path": diff,
         "pairs_above_1e-4": int((per_pair > 1e-4).sum().item()), "pairs": n}}
+
+
+def params_leg(nsof, _lib, ctx, torch, q, prevs, nexts, flow, k, h, w, kernel_ids, steps=3):
+    """The reference's other parameter sets on the first k pairs of the same batch (B: autodriving / tabletennis /
+    uavnew2, C: uav -- /root/reference/data/*/Parameters.txt): whole-step rate, per-kernel time, the roofline of the
+    two dominant kernels on their own algorithmic bytes, and the first pair checked against the CPU oracle."""
+    out_flow = flow[:k]
+    nsof.farneback_batch(prevs, nexts, out_flow, k, h, w, q, ctx=ctx)
+    torch.cuda.synchronize()
+    ctx.prof_enable(*kernel_ids)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nsof.farneback_batch(prevs, nexts, out_flow, k, h, w, q, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = {kid: ctx.prof_collect(kid) for kid in kernel_ids}
+    ctx.prof_enable()
+    alg = algorithmic_bytes_per_pair(nsof, w, h, q)
+    name = _lib.load().nsof_kernel_name
+    rec = {"workload": f"{w}x{h}, pyr_scale={q.pyr_scale}, levels={q.levels}, winsize={q.winsize}, "
+                       f"iterations={q.iterations}, poly_n={q.poly_n}, poly_sigma={q.poly_sigma}",
+           "value": round(k * steps / dt, 2), "unit": "pairs/s", "pairs": k,
+           "kernel_ms_per_step": {name(kid).decode(): round(prof[kid][0] / steps, 3) for kid in kernel_ids},
+           "roofline": {}}
+    for kid in (_lib.K_ITERATE, _lib.K_POLYEXP, _lib.K_PREP):
+        ms, launches = prof[kid]
+        if launches:
+            gbs = alg[kid] * k * steps / (ms * 1e-3) / 1e9
+            rec["roofline"][name(kid).decode()] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                                   "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                   "avg_launch_us": round(ms * 1e3 / launches, 2)}
+    fused = sum(alg[kid] for kid in kernel_ids if prof[kid][1])
+    rec["fused_algorithmic_GBps"] = round(fused * k * steps / dt / 1e9, 1)
+    rec["frac_of_hbm_peak"] = round(fused * k * steps / dt / 1e9 / HBM_PEAK_GBS, 4)
+    from oracle import oracle as O  # noqa: N812  (the checker; only ever used in the CPU legs, tests and smoke())
+    O.build()
+    qa = [getattr(q, a) for a in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    ref = O.farneback(prevs[0].cpu().numpy(), nexts[0].cpu().numpy(), *qa)
+    rec["max_abs_epe_vs_oracle_pair0"] = float(abs(out_flow[0].cpu().numpy() - ref).max())
+    return rec
+
+
+def single_call_leg(nsof, _lib, ctx, torch, p, prevs, nexts, h, w, reps=20):
+    """What a caller that replaces ``cv2.calcOpticalFlowFarneback`` one frame at a time sees (the reference's scripts
+    call it once per frame, /root/reference/optical_flow_seg.py:202-206): milliseconds per lone call, host numpy in
+    -> host numpy out and device-resident, in the default mode and with the opt-in row bands (NSOF_OPT_ROW_BANDS)."""
+    import numpy as np
+    hp, hn = prevs[0].cpu().numpy(), nexts[0].cpu().numpy()
+    kw = p.as_kwargs()
+    one = torch.empty((1, h, w, 2), dtype=torch.float32, device=prevs.device)
+    ids = [_lib.K_PREP, _lib.K_POLYEXP, _lib.K_UPSAMPLE, _lib.K_ITERATE]
+    name = _lib.load().nsof_kernel_name
+    rec, flows = {}, {}
+    for key, bands in (("default", 0), ("row_bands", 1)):
+        ctx.set_option(_lib.OPT_ROW_BANDS, bands)
+        try:
+            for _ in range(3):
+                flows[key] = nsof.calcOpticalFlowFarneback(hp, hn, None, **kw, ctx=ctx)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                nsof.calcOpticalFlowFarneback(hp, hn, None, **kw, ctx=ctx)
+            host_ms = (time.perf_counter() - t0) / reps * 1e3
+            nsof.farneback_batch(prevs, nexts, one, 1, h, w, p, ctx=ctx)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                nsof.farneback_batch(prevs, nexts, one, 1, h, w, p, ctx=ctx)
+            torch.cuda.synchronize()
+            dev_ms = (time.perf_counter() - t0) / reps * 1e3
+            ctx.prof_enable(*ids)
+            nsof.farneback_batch(prevs, nexts, one, 1, h, w, p, ctx=ctx)
+            torch.cuda.synchronize()
+            parts = {name(k).decode(): round(ctx.prof_collect(k)[0], 3) for k in ids}
+            ctx.prof_enable()
+        finally:
+            ctx.set_option(_lib.OPT_ROW_BANDS, 0)
+        rec[key] = {"host_to_host_ms": round(host_ms, 3), "device_resident_ms": round(dev_ms, 3), "kernel_ms": parts}
+    rec["row_bands"]["option"] = "NSOF_OPT_ROW_BANDS=1 (opt-in; column sums restart per band)"
+    rec["row_bands"]["max_abs_vs_default"] = float(np.abs(flows["row_bands"] - flows["default"]).max())
+    rec["workload"] = f"one {w}x{h} pair per call"
+    return rec
 
 
 def config5_leg(nsof, torch, local_rank):

@@ -62,7 +62,14 @@ int nsof_synchronize(nsof_ctx* ctx);
  * leaves the library's operation order.  Same numbers to ~1e-16; where the 2x2 system is rank deficient (real footage,
  * small windows) that decides the flow's 4th decimal, and this mode then equals a CPU restatement of the library bit for bit (about
  * half the throughput: the column sums pass through HBM between two kernels).  Environment default: NSOF_EXACT_ROWSUMS. */
-enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2 };
+/* NSOF_OPT_ROW_BANDS (default 0): for SMALL batches (one call per camera frame, the reference's own call pattern).  The
+ * fused iteration kernel walks an image strip top to bottom in one workgroup, because the library's column sums are one
+ * running sum from row 0; a lone 1080p pair then occupies 8 of 256 compute units.  1 = split every strip into row bands
+ * (automatic height), >= 4 = bands of that many rows: each band starts its column sums with a direct sum of its first
+ * window, which differs from the running sum in the last bits -- the same class of deviation as the row-sum order
+ * above (DESIGN.md section 2 gives the measured end-point difference).  Off by default so that a pair's flow does not
+ * depend on the batch it was part of.  Environment default: NSOF_ROW_BANDS. */
+enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);
 

@@ -771,22 +771,23 @@ struct QGeom {
 template <int MH, int COLS, int GP, int TS, int RR>
 __device__ __forceinline__ void q_produce(RowIn (&in)[2][2], FlowSrc<false>::Raw (&fl)[2][2], float (*mring)[5][COLS],
                                           const Planes& R0, const Planes& R1, const FlowSrc<false>& F, int W, int H, int xc,
-                                          int col, int t)
+                                          int col, int t, int yb)
 {
     constexpr int RL = QGeom<MH, COLS>::RL;
-    const int i = 4 * t + MH + 2 * GP + RR;                  // stream index of this row
+    const int i = 4 * t + MH + 2 * GP + RR;                  // stream index of this row (row yb + i of the image)
     float Mn[5];
-    matrix_from(in[TS][RR], xc, min(i, H - 1), W, H, Mn);
+    matrix_from(in[TS][RR], xc, min(yb + i, H - 1), W, H, Mn);
     const int slot = (i + MH + 1) % RL;
 #pragma unroll
     for (int c = 0; c < 5; c++) mring[slot][c][col] = Mn[c];
-    issue_row(in[TS][RR], R0, R1, W, H, xc, min(i + 8, H - 1), F.resolve(fl[TS][RR]));   // the same row of step t+2
-    fl[TS][RR] = F.fetch(min(i + 16, H - 1));                                            // its flow for step t+4
+    issue_row(in[TS][RR], R0, R1, W, H, xc, min(yb + i + 8, H - 1), F.resolve(fl[TS][RR]));   // the same row of step t+2
+    fl[TS][RR] = F.fetch(min(yb + i + 16, H - 1));                                            // its flow for step t+4
 }
 
 template <int MH, int COLS, int GP>
 __device__ __forceinline__ void q_producer_loop(float (*mring)[5][COLS], const Planes& R0, const Planes& R1,
-                                                const FlowSrc<false>& F, int W, int H, int xc, int col, int nsteps)
+                                                const FlowSrc<false>& F, int W, int H, int xc, int col, int nsteps,
+                                                int yb)
 {
     RowIn in[2][2];
     FlowSrc<false>::Raw fl[2][2];
@@ -794,32 +795,32 @@ __device__ __forceinline__ void q_producer_loop(float (*mring)[5][COLS], const P
     for (int ts = 0; ts < 2; ts++)
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const int r = min(4 * ts + MH + 2 * GP + rr, H - 1);
+            const int r = min(yb + 4 * ts + MH + 2 * GP + rr, H - 1);
             issue_row(in[ts][rr], R0, R1, W, H, xc, r, F.at(r));
         }
 #pragma unroll
     for (int ts = 0; ts < 2; ts++)
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) fl[ts][rr] = F.fetch(min(4 * (ts + 2) + MH + 2 * GP + rr, H - 1));
+        for (int rr = 0; rr < 2; rr++) fl[ts][rr] = F.fetch(min(yb + 4 * (ts + 2) + MH + 2 * GP + rr, H - 1));
     // Barriers (all roles alike): B_init, then B1(t), B2(t) for every step t.
     //   before B_init          both rows of step 0
     //   B_init .. B1(0)        first row of step 1            (consumers: column sums of step 0)
     //   B1(t) .. B2(t)         second row of step t+1         (consumers: row sums + solve of step t)
     //   B2(t) .. B1(t+1)       first row of step t+2          (consumers: column sums of step t+1)
-    q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
-    q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 0);
+    q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 0, yb);
+    q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 0, yb);
     __syncthreads();
-    q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 1);
+    q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 1, yb);
     for (int tb = 0; tb < nsteps; tb += 2) {
         __syncthreads();                                                             // B1(tb)
-        q_produce<MH, COLS, GP, 1, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 1);
+        q_produce<MH, COLS, GP, 1, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 1, yb);
         __syncthreads();                                                             // B2(tb)
-        q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
+        q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2, yb);
         if (tb + 1 >= nsteps) break;
         __syncthreads();                                                             // B1(tb+1)
-        q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2);
+        q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2, yb);
         __syncthreads();                                                             // B2(tb+1)
-        q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 3);
+        q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 3, yb);
     }
 }
 
@@ -829,13 +830,37 @@ template <int MH, int COLS, bool VOUT = false>
 __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* sv_raw, const Planes& R0,
                                                 const Planes& R1, const FlowSrc<false>& F, float2* Fout, size_t fpitch,
                                                 int W, int H, int x0, int xc, int col, int nsteps, double scale,
-                                                double* Vout = nullptr)
+                                                double* Vout, int yb, int ye)
 {
     using G = QGeom<MH, COLS>;
     constexpr int RL = G::RL, SW = G::SW, TPR = COLS / 4;   // TPR solve threads per row
     double (*sv)[5][G::SVW] = reinterpret_cast<double (*)[5][G::SVW]>(sv_raw);   // [4 rows][5 planes]
     double vs[5];
-    {
+    if (yb > 0) {
+        // a row band that starts inside the image (opt-in NSOF_OPT_ROW_BANDS): the window of row yb-1, rows
+        // yb-m-1 .. yb+m-1, is summed directly -- the library's column sums are ONE running sum from row 0, so this
+        // start differs from it in the sums' last bits (same class as the row-sum order).
+        RowIn t[2];
+        const int r0 = max(yb - MH - 1, 0);
+        issue_row(t[0], R0, R1, W, H, xc, r0, F.at(r0));
+#pragma unroll
+        for (int c = 0; c < 5; c++) vs[c] = 0.;
+#pragma unroll
+        for (int j = 0; j <= 2 * MH; j++) {
+            const int r = clampi(yb - MH - 1 + j, 0, H - 1);
+            if (j < 2 * MH) {
+                const int rn = clampi(yb - MH + j, 0, H - 1);
+                issue_row(t[(j + 1) & 1], R0, R1, W, H, xc, rn, F.at(rn));
+            }
+            float Mi[5];
+            matrix_from(t[j & 1], xc, r, W, H, Mi);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                vs[c] += (double)Mi[c];
+                mring[j][c][col] = Mi[c];
+            }
+        }
+    } else {
         // prologue: rows 0..m-1 enter the sums; the m+1 rows above the image replicate row 0.
         // ring slot of stream index i is (i + m + 1) % RL.
         RowIn t;
@@ -875,8 +900,8 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* s
                 const float d = mring[slot_new][c][col] - mring[slot_old][c][col];
                 vs[c] += (double)d;
                 if constexpr (VOUT) {
-                    if (own && 4 * t + q < H)
-                        __builtin_nontemporal_store(vs[c], Vout + ((size_t)(4 * t + q) * 5 + c) * W + (x0 + col - MH));
+                    if (own && yb + 4 * t + q < ye)
+                        __builtin_nontemporal_store(vs[c], Vout + ((size_t)(yb + 4 * t + q) * 5 + c) * W + (x0 + col - MH));
                 } else {
                     sv[q][c][G::svi(col)] = vs[c];
                 }
@@ -889,8 +914,8 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* s
             __syncthreads();   // B2(t): same barrier sequence as the solving variant
             continue;
         }
-        const int yo = 4 * t + hrow, xo = x0 + 4 * t4;
-        if (4 * t4 < SW && yo < H && xo < W) {
+        const int yo = yb + 4 * t + hrow, xo = x0 + 4 * t4;
+        if (4 * t4 < SW && yo < ye && xo < W) {
             const double (*svr)[G::SVW] = sv[hrow];
             auto at = [&](int c, int j) { return svr[c][(j & 3) * G::SVSUB + t4 + (j >> 2)]; };   // column 4 t4 + j
             double g[5];
@@ -934,7 +959,7 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
                                                     size_t pair_stride, const float* __restrict__ flow_in,
                                                     float* __restrict__ flow_out, int W, int H, int block_size,
                                                     const nsof_het_item* __restrict__ items, int het_final,
-                                                    double* __restrict__ vsum_out = nullptr)
+                                                    double* __restrict__ vsum_out = nullptr, int band_rows = 0)
 {
     using G = QGeom<MH, COLS>;
     constexpr int SW = G::SW;
@@ -966,7 +991,7 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
     } else {
 #ifndef NSOF_NO_XCD_REMAP
         const unsigned total = gridDim.x * gridDim.z;   // an XCD owns whole pairs (see k_iterate_pc)
-        if ((total & 7u) == 0) {
+        if ((total & 7u) == 0 && gridDim.y == 1) {
             const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
             const unsigned j = (lin & 7u) * (total >> 3) + (lin >> 3);
             pair = (int)(j / gridDim.x);
@@ -984,14 +1009,22 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
     F.W = (unsigned)W;
     F.xc = (unsigned)xc;
     float2* Fout = reinterpret_cast<float2*>(flow_out) + (size_t)pair * plane;
-    const int nsteps = (H + 3) / 4;
+    // band_rows > 0 (a multiple of 4): blockIdx.y owns rows [yb, ye) only -- more workgroups for a small batch
+    int yb = 0, ye = H;
+    if (band_rows > 0) {
+        yb = blockIdx.y * band_rows;
+        ye = min(H, yb + band_rows);
+        if (yb >= H) return;   // block-uniform, before any barrier
+    }
+    const int nsteps = (ye - yb + 3) / 4;
     if (role == 0)
         q_consumer_loop<MH, COLS, VOUT>(mring, sv, R0, R1, F, Fout, fpitch, W, H, x0, xc, col, nsteps,
-                                        1. / (block_size * block_size), VOUT ? vsum_out + (size_t)pair * 5 * plane : nullptr);
+                                        1. / (block_size * block_size), VOUT ? vsum_out + (size_t)pair * 5 * plane : nullptr,
+                                        yb, ye);
     else if (role == 1)
-        q_producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps);
+        q_producer_loop<MH, COLS, 0>(mring, R0, R1, F, W, H, xc, col, nsteps, yb);
     else
-        q_producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps);
+        q_producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps, yb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1166,8 +1199,22 @@ int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R
     using G = QGeom<MH>;
     if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false>, G::SMEM)) return rc;
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
+    // Opt-in row bands (NSOF_OPT_ROW_BANDS): a small batch has too few (strip, pair) workgroups for 256 CUs and each
+    // walks the whole height; bands of rows add workgroups at the price of 2m+1 extra rows per band.  1 = automatic
+    // (bands no shorter than 32 rows, until the launch has about two workgroups per CU), >= 4 = that many rows.
+    int band_rows = 0;
+    if (ctx->opt_row_bands > 0) {
+        if (ctx->opt_row_bands >= 4) {
+            band_rows = (ctx->opt_row_bands + 3) & ~3;
+        } else {
+            const int want = (512 + (int)(grid.x * grid.z) - 1) / (int)(grid.x * grid.z);   // bands per strip
+            band_rows = std::max(32, ((H + want - 1) / want + 3) & ~3);
+        }
+        if (band_rows >= H) band_rows = 0;
+    }
+    if (band_rows > 0) grid.y = (H + band_rows - 1) / band_rows;
     hipLaunchKernelGGL((k_iterate_q<MH, false>), grid, dim3(768), G::SMEM, ctx->stream, R0, R1, pair_stride, flow_in,
-                       flow_out, W, H, winsize, nullptr, 0);
+                       flow_out, W, H, winsize, nullptr, 0, nullptr, band_rows);
     return NSOF_OK;
 }
 

@@ -186,6 +186,7 @@ extern "C" int nsof_create(int device, nsof_ctx** out)
     ctx->stream = ctx->own_stream;
     if (const char* e = getenv("NSOF_POLYEXP_F32")) ctx->opt_polyexp_f32 = (e[0] && e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("NSOF_EXACT_ROWSUMS")) ctx->opt_exact_rowsums = (e[0] && e[0] != '0') ? 1 : 0;
+    if (const char* e = getenv("NSOF_ROW_BANDS")) ctx->opt_row_bands = std::max(0, atoi(e));
     *out = ctx;
     return NSOF_OK;
 }
@@ -235,6 +236,11 @@ extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
         ctx->opt_exact_rowsums = value ? 1 : 0;
         return NSOF_OK;
     }
+    if (option == NSOF_OPT_ROW_BANDS) {
+        if (value < 0) return nsof_set_error(ctx, NSOF_EINVAL, "NSOF_OPT_ROW_BANDS: 0 (off), 1 (automatic) or a row count");
+        ctx->opt_row_bands = value;
+        return NSOF_OK;
+    }
     return nsof_set_error(ctx, NSOF_EINVAL, "unknown option %d", option);
 }
 
@@ -247,6 +253,10 @@ extern "C" int nsof_get_option(const nsof_ctx* ctx, int option, int* value)
     }
     if (option == NSOF_OPT_EXACT_ROWSUMS) {
         *value = ctx->opt_exact_rowsums;
+        return NSOF_OK;
+    }
+    if (option == NSOF_OPT_ROW_BANDS) {
+        *value = ctx->opt_row_bands;
         return NSOF_OK;
     }
     return NSOF_EINVAL;

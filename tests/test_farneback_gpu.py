@@ -426,3 +426,46 @@ def test_polyexp_float_mode_is_opt_in_and_close(ctx, nsof_lib, torch_dev):
     assert not np.array_equal(re, rf)                       # it IS a different arithmetic ...
     assert float(np.abs(re - rf).max()) <= 2e-5 * float(np.abs(re).max())   # ... within float rounding of the sums
     assert float(np.abs(f_fast - f_exact).max()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_row_bands_mode_is_opt_in_and_close(ctx, nsof_lib, oracle):
+    """NSOF_OPT_ROW_BANDS (low-latency mode for lone calls): off by default; on, every strip of the iteration kernel is
+    cut into row bands whose column sums start from a direct sum instead of the library's running sum from row 0 --
+    same numbers to ~1e-16, hence a flow that stays inside the oracle tolerance on textured frames (params A, wide
+    window) and moves in the 4th decimal where 3x3 windows are rank deficient (params B; same sensitivity as the
+    row-sum order).  Ragged last bands, bands shorter than the window, and images shorter than
+    one band (no split: bit-identical to the default) are covered."""
+    from nsof import _lib, synth
+    assert ctx.get_option(_lib.OPT_ROW_BANDS) == 0
+    assert ctx._lib.nsof_set_option(ctx.ptr, _lib.OPT_ROW_BANDS, -1) == _lib.NSOF_EINVAL
+    ns = 1e-4   # the north-star tolerance (max-abs end-point error)
+    cases = [((1080, 1920), A, 1, ns), ((203, 317), A, 32, ns), ((203, 317), A, 4, ns),
+             ((135, 240), Cc, 8, 1e-3), ((801, 801), B, 1, 1e-3), ((30, 200), A, 32, 0.0)]
+    for (h, w), params, bands, tol in cases:
+        prev, nxt = synth.make_pair(4242 + h, h, w)
+        base = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
+        ctx.set_option(_lib.OPT_ROW_BANDS, bands)
+        try:
+            assert ctx.get_option(_lib.OPT_ROW_BANDS) == bands
+            got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
+        finally:
+            ctx.set_option(_lib.OPT_ROW_BANDS, 0)
+        if tol == 0.0:
+            assert np.array_equal(got, base)
+            continue
+        want = oracle.farneback(prev, nxt, *params)
+        err, dev = float(np.abs(got - want).max()), float(np.abs(got - base).max())
+        assert err <= tol and dev <= tol, f"{(h, w)} bands={bands}: vs oracle {err}, vs default {dev}"
+    # the keyword of the drop-in switches it per call and restores the context's setting
+    prev, nxt = synth.make_pair(7, 270, 480)
+    a = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=ctx, low_latency=True)
+    assert ctx.get_option(_lib.OPT_ROW_BANDS) == 0
+    ctx.set_option(_lib.OPT_ROW_BANDS, 1)
+    try:
+        b = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=ctx)
+        c = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=ctx, exact=True)   # exact order ignores bands
+    finally:
+        ctx.set_option(_lib.OPT_ROW_BANDS, 0)
+    assert np.array_equal(a, b)
+    assert np.array_equal(c, oracle.farneback(prev, nxt, *A))
