@@ -263,6 +263,8 @@ def main():
         if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
             out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
         if world == 1 and args.mode == "pairs" and not args.no_param_legs:
+            out["sequence"] = sequence_leg(nsof, ctx, torch, p, prevs, nexts, flow, n, h, w, max(2, min(args.steps, 5)))
+        if world == 1 and args.mode == "pairs" and not args.no_param_legs:
             out["single_call"] = single_call_leg(nsof, _lib, ctx, torch, p, prevs, nexts, h, w)
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
@@ -316,7 +318,7 @@ def params_leg(nsof, _lib, ctx, torch, q, prevs, nexts, flow, k, h, w, kernel_id
     """The reference's other parameter sets on the first k pairs of the same batch (B: autodriving / tabletennis /
     uavnew2, C: uav -- /root/reference/data/*/Parameters.txt): whole-step rate, per-kernel time, the roofline of the
     two dominant kernels on their own algorithmic bytes, and the first pair checked against the CPU oracle."""
-    out_flow = flow[:k]
+    out_flow = torch.empty_like(flow[:k])   # `flow` keeps the headline result: the CPU leg checks it later
     nsof.farneback_batch(prevs, nexts, out_flow, k, h, w, q, ctx=ctx)
     torch.cuda.synchronize()
     ctx.prof_enable(*kernel_ids)
@@ -349,7 +351,30 @@ def params_leg(nsof, _lib, ctx, torch, q, prevs, nexts, flow, k, h, w, kernel_id
     qa = [getattr(q, a) for a in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
     ref = O.farneback(prevs[0].cpu().numpy(), nexts[0].cpu().numpy(), *qa)
     rec["max_abs_epe_vs_oracle_pair0"] = float(abs(out_flow[0].cpu().numpy() - ref).max())
+    del out_flow
+    torch.cuda.empty_cache()
     return rec
+
+
+def sequence_leg(nsof, ctx, torch, p, prevs, nexts, flow, n, h, w, steps):
+    """The reference's own workload shape: CONSECUTIVE frames of one video (/root/reference/optical_flow_seg.py walks
+    frame i -> i+1), through nsof_farneback_u8_sequence_dev -- pyramid and polynomial expansion are computed once
+    per frame instead of once per pair side.  n+1 frames -> n flow fields; flow i must equal the pair call on
+    (frame i, frame i+1)."""
+    frames = torch.cat([prevs, nexts[-1:]], 0).contiguous()   # frame i+1 = 'next' of pair i only for the last one ...
+    out = torch.empty_like(flow)
+    nsof.farneback_sequence(frames, out, n + 1, h, w, p, ctx=ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nsof.farneback_sequence(frames, out, n + 1, h, w, p, ctx=ctx)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # ... so the check uses the last pair, whose two frames are the batch's last (prev, next)
+    same = bool(torch.equal(out[n - 1], flow[n - 1]))
+    return {"value": round(n * steps / dt, 2), "unit": "pairs/s", "frames": n + 1,
+            "path": "nsof_farneback_u8_sequence_dev (per-frame stages shared between neighbouring pairs)",
+            "last_pair_identical_to_pair_call": same}
 
 
 def single_call_leg(nsof, _lib, ctx, torch, p, prevs, nexts, h, w, reps=20):

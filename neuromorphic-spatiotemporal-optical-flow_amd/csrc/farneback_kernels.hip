@@ -902,6 +902,182 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 }
 
 // ---------------------------------------------------------------------------------------
+// Role-specialised strip walker (the default for the exact arithmetic): the same two passes, same arithmetic and order
+// as k_polyexp, run by different waves.  A workgroup has 8 waves: waves 0-3 (thread <-> column) run the vertical pass
+// of step t+1 while waves 4-7 (wave <-> row, lane <-> 4 pixels) run the horizontal pass of step t on the other half of
+// the double-buffered moment rows; one barrier per step.  Neither role carries the other's registers across its
+// pass (the column window of 2N+1 rows on one side, the moment window and the double taps on the other), so the
+// taps stay in scalar registers and radius 10 fits 4 waves per SIMD where the single-role kernel spilled at 256.
+// ---------------------------------------------------------------------------------------
+template <int N, bool HET>
+__global__ __launch_bounds__(512) void k_polyexp_rs(const float* __restrict__ img, float* __restrict__ R, int W, int H,
+                                                     int seg_rows, nsof_poly_taps tp,
+                                                     const nsof_het_item* __restrict__ items)
+{
+    using G = PolyGeom<N>;
+    size_t img_off, r_off;   // element offsets of this image / its expansion
+    if constexpr (HET) {
+        const nsof_het_item& it = items[blockIdx.z >> 1];
+        const size_t which = blockIdx.z & 1;
+        W = it.wk;
+        H = it.hk;
+        if (blockIdx.x * G::SW >= W || blockIdx.y * seg_rows >= H) return;   // block-uniform, before any barrier
+        img_off = it.offI + which * (size_t)W * H;
+        r_off = it.offR + which * 5 * (size_t)W * H;
+    } else {
+        img_off = (size_t)blockIdx.z * W * H;
+        r_off = (size_t)blockIdx.z * 5 * W * H;
+    }
+    __shared__ __attribute__((aligned(16))) float sr[2][3][4][256];
+    __shared__ float4 st[4][256];   // per-wave transpose buffer for the interleaved channel-0..3 stores
+
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // within the role
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    const int x0 = blockIdx.x * G::SW;
+    const int ys = blockIdx.y * seg_rows, ye = min(ys + seg_rows, H);
+    const int nsteps = (ye - ys + 3) / 4;
+    const unsigned plane = (unsigned)W * (unsigned)H;
+
+    if (role == 0) {
+        // ---- vertical pass: 4 rows per step for this thread's column
+        const char* Ib = reinterpret_cast<const char*>(img + img_off);
+        const int xc = clampi(x0 - G::NP + tid, 0, W - 1);
+        auto ld = [&](int row) {
+            return *reinterpret_cast<const float*>(Ib + ((unsigned)clampi(row, 0, H - 1) * (unsigned)W + (unsigned)xc) * 4u);
+        };
+        float win[2 * N + 1];   // win[j] = I[clamp(y - N + j)][xc]
+#pragma unroll
+        for (int j = 0; j <= 2 * N; j++) win[j] = ld(ys - N + j);
+        float pre[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) pre[q] = ld(ys + 1 + N + q);
+        for (int t = 0; t <= nsteps; t++) {
+            if (t < nsteps) {
+                const int y = ys + 4 * t, buf = t & 1;
+                float nxt[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) nxt[q] = ld(y + 5 + N + q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float t0 = win[N] * tp.g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int k = 1; k <= N; k++) {
+                        const float a = win[N - k], b = win[N + k];
+                        float p = a + b;
+                        t0 = t0 + tp.g[k] * p;
+                        t2 = t2 + tp.xxg[k] * p;
+                        p = b - a;
+                        t1 = t1 + tp.xg[k] * p;
+                    }
+                    sr[buf][0][q][tid] = t0;
+                    sr[buf][1][q][tid] = t1;
+                    sr[buf][2][q][tid] = t2;
+#pragma unroll
+                    for (int j = 0; j < 2 * N; j++) win[j] = win[j + 1];
+                    win[2 * N] = pre[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) pre[q] = nxt[q];
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- horizontal pass: wave <-> row, lane <-> 4 pixels, one step behind the vertical pass
+    char* Rb = reinterpret_cast<char*>(R + r_off);
+    for (int t = 0; t <= nsteps; t++) {
+        if (t >= 1) {
+            const int y = ys + 4 * (t - 1), buf = (t - 1) & 1;
+            const int yo = y + wave;
+            const int xo = x0 + 4 * lane;
+            if (4 * lane < G::SW && yo < ye && xo < W) {
+                const unsigned opix = (unsigned)yo * (unsigned)W + (unsigned)xo;
+                auto load_row = [&](int a, float (&v)[4 * G::NV]) {
+                    const float4* p4 = reinterpret_cast<const float4*>(&sr[buf][a][wave][4 * lane]);
+#pragma unroll
+                    for (int i = 0; i < G::NV; i++) {
+                        const float4 f = p4[i];
+                        v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w;
+                    }
+                };
+                double t03[4];  // b1 * ig03, shared by the xx and yy outputs
+                float o0[4], o1[4], o2[4], o3[4], o4[4];
+                {
+                    float v[4 * G::NV];
+                    load_row(0, v);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c = G::NP + p;
+                        double a1 = (double)(v[c] * tp.g[0]), a2 = 0, a4 = 0;
+#pragma unroll
+                        for (int k = 1; k <= N; k++) {
+                            const float hi = v[c + k], lo = v[c - k];
+                            const double tg = (double)(hi + lo);
+                            a1 = fma(tg, tp.dg[k], a1);     // product of two float-valued doubles is exact
+                            a4 = fma(tg, tp.dxxg[k], a4);
+                            a2 += (double)((hi - lo) * tp.xg[k]);
+                        }
+                        t03[p] = a1 * tp.ig03;
+                        o1[p] = (float)(a2 * tp.ig11);
+                        o3[p] = (float)(t03[p] + a4 * tp.ig33);
+                    }
+                }
+                {
+                    float v[4 * G::NV];
+                    load_row(1, v);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c = G::NP + p;
+                        double a3 = (double)(v[c] * tp.g[0]), a6 = 0;
+#pragma unroll
+                        for (int k = 1; k <= N; k++) {
+                            const float hi = v[c + k], lo = v[c - k];
+                            a3 += (double)((hi + lo) * tp.g[k]);
+                            a6 += (double)((hi - lo) * tp.xg[k]);
+                        }
+                        o0[p] = (float)(a3 * tp.ig11);
+                        o4[p] = (float)(a6 * tp.ig55);
+                    }
+                }
+                {
+                    float v[4 * G::NV];
+                    load_row(2, v);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int c = G::NP + p;
+                        double a5 = (double)(v[c] * tp.g[0]);
+#pragma unroll
+                        for (int k = 1; k <= N; k++) a5 += (double)((v[c + k] + v[c - k]) * tp.g[k]);
+                        o2[p] = (float)(t03[p] + a5 * tp.ig33);
+                    }
+                }
+                float* c4 = reinterpret_cast<float*>(Rb) + 4u * plane + opix;
+                if ((W & 3) == 0) {
+                    nsof_store_stream4(c4, o4[0], o4[1], o4[2], o4[3]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (xo + p < W) c4[p] = o4[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; p++) st[wave][4 * lane + (p ^ ((lane >> 1) & 3))] = make_float4(o0[p], o1[p], o2[p], o3[p]);
+            }
+            {
+                float4* q4 = reinterpret_cast<float4*>(Rb) + (unsigned)yo * (unsigned)W + (unsigned)x0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int px = 64 * k + lane;   // pixel within the strip row
+                    const float4 v = st[wave][(px & ~3) | ((px & 3) ^ ((px >> 3) & 3))];
+                    if (px < G::SW && yo < ye && x0 + px < W) nsof_store_stream4(reinterpret_cast<float*>(q4 + px), v.x, v.y, v.z, v.w);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // FarnebackUpdateMatrices: one thread per pixel.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_matrices(const float* __restrict__ R0b, const float* __restrict__ R1b,
@@ -1339,11 +1515,14 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
+    static const bool mono = [] { const char* e = getenv("NSOF_POLYEXP"); return e && e[0] == 'm'; }();   // A/B: single-role kernel
     if (ctx->opt_polyexp_f32)
         hipLaunchKernelGGL((k_polyexp<N, false, true>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps,
                            nullptr);
-    else
+    else if (mono)
         hipLaunchKernelGGL((k_polyexp<N, false>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
+    else
+        hipLaunchKernelGGL((k_polyexp_rs<N, false>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
 }
 
 // Work-list twin: W, H are the largest level extents over the table, n_img = 2 * items.
@@ -1358,7 +1537,7 @@ void launch_polyexp_het_n(nsof_ctx* ctx, int n_img, const nsof_het_item* items, 
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
-    hipLaunchKernelGGL((k_polyexp<N, true>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, items);
+    hipLaunchKernelGGL((k_polyexp_rs<N, true>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, items);
 }
 
 }  // namespace

@@ -43,3 +43,12 @@ def test_bench_json_contract():
     assert a["roofline_fused_bytes"]["frac"] > 0 and a["roofline_survey_definition"]["bytes_per_slice"] > 6e7
     assert d["config5"]["flow_finite"] is True and d["config5"]["surface_frames"] >= 2
     assert d["parity_ok"] is True
+    # the other two parameter sets of the reference's datasets, consecutive-frame mode, lone-call latency
+    for key in ("params_B", "params_C"):
+        q = d[key]
+        assert q["unit"] == "pairs/s" and q["value"] > 0 and q["max_abs_epe_vs_oracle_pair0"] <= d["epe_tolerance"]
+        assert 0 < q["roofline"]["iterate"]["frac"] < 1 and 0 < q["roofline"]["polyexp"]["frac"] < 1
+    assert d["sequence"]["value"] > 0 and d["sequence"]["last_pair_identical_to_pair_call"] is True
+    sc = d["single_call"]
+    assert sc["default"]["host_to_host_ms"] > 0 and sc["row_bands"]["device_resident_ms"] > 0
+    assert sc["row_bands"]["max_abs_vs_default"] < 1e-3
