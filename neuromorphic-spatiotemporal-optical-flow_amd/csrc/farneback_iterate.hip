@@ -753,6 +753,32 @@ int lds_opt_in(nsof_ctx* ctx, K kernel, size_t bytes)
 // Arithmetic per pixel and its order are those of k_iterate_pc (pixels 4k+2, 4k+3 of a row reach their row sums by
 // sliding instead of by a direct sum: same double-precision values up to their last bit).
 // ---------------------------------------------------------------------------------------------
+#ifdef NSOF_Q_TIMING
+// Tuning build only (scripts/build_variant.sh ... -DNSOF_Q_TIMING): shader-clock time that one wave of each role of
+// workgroup (0,0,0) spends working and waiting at the two barriers of a step; read back by scripts/q_timing.py.
+__device__ unsigned long long g_qt[16];
+#define QT_ON (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 255) == 0)
+#define QT_DECL unsigned long long qt_prev = __builtin_amdgcn_s_memtime()
+#define QT_MARK(slot)                                                      \
+    do {                                                                   \
+        const unsigned long long qt_now = __builtin_amdgcn_s_memtime();    \
+        if (QT_ON) atomicAdd(&g_qt[slot], qt_now - qt_prev);               \
+        qt_prev = qt_now;                                                  \
+    } while (0)
+extern "C" int nsof_debug_qtiming(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_qt), sizeof(g_qt)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_qt), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define QT_DECL
+#define QT_MARK(slot)
+#endif
+
 template <int MH, int COLS_ = 256>
 struct QGeom {
     static constexpr int COLS = COLS_, RB = 4;
@@ -811,15 +837,24 @@ __device__ __forceinline__ void q_producer_loop(float (*mring)[5][COLS], const P
     q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, 0, yb);
     __syncthreads();
     q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, 1, yb);
+    QT_DECL;
     for (int tb = 0; tb < nsteps; tb += 2) {
+        QT_MARK(4 + 4 * GP + 2);                                                     // work before B1
         __syncthreads();                                                             // B1(tb)
+        QT_MARK(4 + 4 * GP + 3);                                                     // wait at B1
         q_produce<MH, COLS, GP, 1, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 1, yb);
+        QT_MARK(4 + 4 * GP + 0);                                                     // work before B2
         __syncthreads();                                                             // B2(tb)
+        QT_MARK(4 + 4 * GP + 1);                                                     // wait at B2
         q_produce<MH, COLS, GP, 0, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2, yb);
         if (tb + 1 >= nsteps) break;
+        QT_MARK(4 + 4 * GP + 2);
         __syncthreads();                                                             // B1(tb+1)
+        QT_MARK(4 + 4 * GP + 3);
         q_produce<MH, COLS, GP, 0, 1>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 2, yb);
+        QT_MARK(4 + 4 * GP + 0);
         __syncthreads();                                                             // B2(tb+1)
+        QT_MARK(4 + 4 * GP + 1);
         q_produce<MH, COLS, GP, 1, 0>(in, fl, mring, R0, R1, F, W, H, xc, col, tb + 3, yb);
     }
 }
@@ -891,6 +926,7 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* s
     int slot_new = (2 * MH + 1) % RL;           // stream index m    -> slot 2m+1
     int slot_old = 0;                           // stream index -m-1 -> slot 0
     const bool own = col >= MH && col < MH + SW && x0 + col - MH < W;   // VOUT: this thread's column belongs to the strip
+    QT_DECL;
     for (int t = 0; t < nsteps; t++) {
         // column sums: four more rows enter the window of this thread's column
 #pragma unroll
@@ -909,7 +945,9 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* s
             slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
             slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
         }
+        QT_MARK(0);        // column sums
         __syncthreads();   // B1(t): column sums of step t visible
+        QT_MARK(1);        // wait at B1
         if constexpr (VOUT) {
             __syncthreads();   // B2(t): same barrier sequence as the solving variant
             continue;
@@ -950,7 +988,9 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* s
                     if (xo + p < W) dst[p] = o[p];
             }
         }
+        QT_MARK(2);        // row sums + solve
         __syncthreads();   // B2(t): column sums consumed, the buffer may be rewritten
+        QT_MARK(3);        // wait at B2
     }
 }
 

@@ -29,7 +29,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if m and r["Counter_Name"] == c:
             acc[m.group(1)][c].append(float(r["Counter_Value"]))
 px, n = 1920 * 1080, 32
-alg = {"k_polyexp": 2 * n * px * 24, "k_iterate_q": n * px * 56, "k_iterate_pc": n * px * 56,
+alg = {"k_polyexp": 2 * n * px * 24, "k_polyexp_rs": 2 * n * px * 24, "k_iterate_q": n * px * 56, "k_iterate_pc": n * px * 56,
        "k_flow_upsample_walk": n * 8 * (px + 960 * 540), "k_prep_same3_vec": 2 * n * px * 5}
 out = {"_doc": "HBM bytes per launch from rocprofv3 PMC (scripts/prof_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate "
                "passes over scripts/stage_bench.py --pairs 32, 1920x1080 level-0 launches, smooth flow; median over "
@@ -37,7 +37,7 @@ out = {"_doc": "HBM bytes per launch from rocprofv3 PMC (scripts/prof_traffic.sh
                "FETCH_SIZE reports half the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is "
                "exact for 16-B streaming stores.  bench.py scales its algorithmic bytes per launch by "
                "traffic_over_algorithmic and labels the result as an estimate.", "round": 2, "kernels": {}}
-names = {"k_polyexp": "polyexp", "k_iterate_q": "iterate", "k_iterate_pc": "iterate_pc", "k_flow_upsample_walk": "flow_upsample",
+names = {"k_polyexp": "polyexp_mono", "k_polyexp_rs": "polyexp", "k_iterate_q": "iterate", "k_iterate_pc": "iterate_pc", "k_flow_upsample_walk": "flow_upsample",
          "k_prep_same3_vec": "prep"}
 for k, v in acc.items():
     if k not in alg or not v["FETCH_SIZE"] or not v["WRITE_SIZE"]:
