@@ -154,6 +154,10 @@ int nsof_stage_pyr_level(nsof_ctx* ctx, int n_img, const uint8_t* d_src, ptrdiff
                          ptrdiff_t img_stride, int width, int height, double pyr_scale, int level, float* d_out);
 int nsof_stage_polyexp(nsof_ctx* ctx, int n_img, const float* d_img, int width, int height,
                        int poly_n, double poly_sigma, float* d_R);
+/* Diagnostic: d_out[i] = the reciprocal the 2x2 solves use (rcp + Newton steps + residual correction, without the
+ * scaling / fix-up instructions of a general division) and d_ieee[i] = 1.0 / d_x[i] as the compiler divides; the test
+ * asserts they are the same bits over the determinants' range. */
+int nsof_stage_recip(nsof_ctx* ctx, long long n, const double* d_x, double* d_out, double* d_ieee);
 /* n_pairs pairs: R holds [n_pairs][2][5][h][w] (image 0 = prev, 1 = next). */
 int nsof_stage_update_matrices(nsof_ctx* ctx, int n_pairs, const float* d_R, const float* d_flow,
                                int width, int height, float* d_M);

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_iterate(const float* __restrict__ R0
                     }
                     const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
                     const double h1 = g[3] * scale, h2 = g[4] * scale;
-                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
                     o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
                     o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
                 }
@@ -596,7 +596,7 @@ __device__ __forceinline__ void consumer_loop(float (*mring)[5][COLS], void* sv_
                 }
                 const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
                 const double h1 = g[3] * scale, h2 = g[4] * scale;
-                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
                 o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
                 o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
             }
@@ -974,7 +974,7 @@ __device__ __forceinline__ void q_consumer_loop(float (*mring)[5][COLS], void* s
                 }
                 const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
                 const double h1 = g[3] * scale, h2 = g[4] * scale;
-                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
                 o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
                 o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
             }
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rowscan_solve(const double* __re
                 if (x < W && y < H) {
                     const double g11 = St[0][r][px] * scale, g12 = St[1][r][px] * scale, g22 = St[2][r][px] * scale;
                     const double h1 = St[3][r][px] * scale, h2 = St[4][r][px] * scale;
-                    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
                     Fout[(size_t)y * fpitch + x] =
                         make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
                 }

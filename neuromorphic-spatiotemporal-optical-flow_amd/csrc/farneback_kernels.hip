@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float* __restrict__ M,
                 }
                 const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
                 const double h1 = g[3] * scale, h2 = g[4] * scale;
-                const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
                 o[p].x = (float)((g11 * h2 - g12 * h1) * idet);
                 o[p].y = (float)((g22 * h1 - g12 * h2) * idet);
             }
@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(64) void k_blur_rowsolve(const double* __restrict__
         for (int c = 0; c < 5; c++) g[c] += at(c, x + m) - at(c, x - m - 1);
         const double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale;
         const double h1 = g[3] * scale, h2 = g[4] * scale;
-        const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+        const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
         fz[x] = make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
     }
 }

@@ -443,6 +443,23 @@ extern "C" int nsof_stage_pyr_level(nsof_ctx* ctx, int n_img, const uint8_t* d_s
     return nsof_launch_prep(ctx, n_img, d_src, row_stride, img_stride, width, height, wk, hk, taps, d_out);
 }
 
+__global__ void k_recip_probe(long long n, const double* __restrict__ x, double* __restrict__ fast, double* __restrict__ ieee)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        fast[i] = nsof_recip_normal(x[i]);
+        ieee[i] = 1. / x[i];
+    }
+}
+
+extern "C" int nsof_stage_recip(nsof_ctx* ctx, long long n, const double* d_x, double* d_out, double* d_ieee)
+{
+    if (!ctx || !d_x || !d_out || !d_ieee || n < 1) return NSOF_EINVAL;
+    hipLaunchKernelGGL(k_recip_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_x, d_out, d_ieee);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
 extern "C" int nsof_stage_polyexp(nsof_ctx* ctx, int n_img, const float* d_img, int width, int height, int poly_n,
                                   double poly_sigma, float* d_R)
 {

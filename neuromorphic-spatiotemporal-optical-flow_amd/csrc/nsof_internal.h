@@ -176,6 +176,22 @@ int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, co
 #ifdef __HIPCC__
 typedef float nsof_f4v __attribute__((ext_vector_type(4)));
 typedef float nsof_f2v __attribute__((ext_vector_type(2)));
+// 1/x, correctly rounded, for a NORMAL x whose reciprocal is normal too (the determinant + 1e-3 of the 2x2 systems: between
+// ~1e-3 and ~1e20 for 8-bit frames).  This is the division sequence the compiler emits for 1./x -- v_rcp_f64, two Newton
+// steps, the residual correction of the quotient -- without the operand scaling and special-case fix-ups
+// (v_div_scale / v_div_fmas / v_div_fixup: 5 of the 12 instructions) that only matter for subnormal, huge or non-finite
+// operands.  Bit-identical to IEEE division on that range (tests/test_farneback_gpu.py::test_recip_matches_ieee_division).
+__device__ __forceinline__ double nsof_recip_normal(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);   // residual of the quotient q0 = 1 * r
+    return __builtin_fma(e, r, r);
+}
+
 __device__ __forceinline__ void nsof_store_stream4(float* p, float a, float b, float c, float d)
 {
 #ifndef NSOF_PLAIN_STORES

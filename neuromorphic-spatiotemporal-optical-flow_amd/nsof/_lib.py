@@ -52,6 +52,7 @@ SIGNATURES = {
     "nsof_farneback_level_size": (_i, [_i, _i, _d, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_d)]),
     "nsof_stage_pyr_level": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _d, _i, _vp]),
     "nsof_stage_polyexp": (_i, [_vp, _i, _vp, _i, _i, _i, _d, _vp]),
+    "nsof_stage_recip": (_i, [_vp, C.c_longlong, _vp, _vp, _vp]),
     "nsof_stage_update_matrices": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "nsof_stage_blur_solve": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "nsof_stage_iterate": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp]),

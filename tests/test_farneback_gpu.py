@@ -469,3 +469,29 @@ def test_row_bands_mode_is_opt_in_and_close(ctx, nsof_lib, oracle):
         ctx.set_option(_lib.OPT_ROW_BANDS, 0)
     assert np.array_equal(a, b)
     assert np.array_equal(c, oracle.farneback(prev, nxt, *A))
+
+
+@pytest.mark.gpu
+def test_recip_matches_ieee_division(ctx, torch_dev):
+    """The 2x2 solves take 1/det from nsof_recip_normal (the compiler's own division sequence minus its operand
+    scaling and special-case fix-ups).  Over the determinants' range and far beyond it -- 2^-900 .. 2^900, 64 M
+    log-uniform values plus mantissa edge cases -- it returns the bits of IEEE division."""
+    import torch
+    g = torch.Generator(device=torch_dev).manual_seed(5)
+    n = 1 << 24
+    for rep in range(4):
+        e = torch.rand(n, dtype=torch.float64, device=torch_dev, generator=g) * (1800.0 if rep else 110.0) - (900.0 if rep else 10.0)
+        x = torch.exp2(torch.floor(e)) * (1.0 + torch.rand(n, dtype=torch.float64, device=torch_dev, generator=g))
+        if rep == 3:   # mantissas next to a power of two and all-ones, exact powers of two
+            k = torch.arange(n, device=torch_dev) % 4
+            m = torch.where(k == 0, torch.tensor(1.0, dtype=torch.float64, device=torch_dev),
+                            torch.where(k == 1, torch.tensor(2.0 - 2.0 ** -52, dtype=torch.float64, device=torch_dev),
+                                        torch.where(k == 2, torch.tensor(1.0 + 2.0 ** -52, dtype=torch.float64, device=torch_dev),
+                                                    torch.tensor(1.5, dtype=torch.float64, device=torch_dev))))
+            x = torch.exp2(torch.floor(e)) * m
+        fast, ieee = torch.empty_like(x), torch.empty_like(x)
+        torch.cuda.synchronize()
+        ctx.check(ctx._lib.nsof_stage_recip(ctx.ptr, n, x.data_ptr(), fast.data_ptr(), ieee.data_ptr()))
+        ctx.synchronize()
+        assert torch.equal(fast.view(torch.int64), ieee.view(torch.int64)), f"rep {rep}"
+        assert torch.equal(ieee, 1.0 / x)
