@@ -554,6 +554,33 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         return NSOF_OK;
     }
 
+    {
+        // A batch whose workspace (116 B/px/pair: level images, expansions, second flow buffer; + matrices / column sums
+        // in the unfused / exact forms) would not fit the device's free memory is run in chunks of as many pairs as do
+        // fit -- same kernels on sub-ranges of the same buffers, so the result does not depend on the chunking.
+        // NSOF_MAX_PAIRS caps the chunk by hand (tests).
+        const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact ? 40 : 0)) + 4096;
+        size_t free_b = 0, total_b = 0;
+        NSOF_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+        size_t fit = (size_t)((double)(free_b + ctx->ws_bytes) * 0.92) / per_pair;
+        if (const char* e = getenv("NSOF_MAX_PAIRS")) {
+            const long v = atol(e);
+            if (v >= 1 && (size_t)v < fit) fit = (size_t)v;
+        }
+        if (fit < 1) fit = 1;
+        if ((size_t)n_pairs > fit) {
+            for (int i = 0; i < n_pairs; i += (int)fit) {
+                const int nb = n_pairs - i < (int)fit ? n_pairs - i : (int)fit;
+                rc = nsof_farneback_core(ctx, sequence, nb, d_prev + (ptrdiff_t)i * pair_stride,
+                                         d_next + (ptrdiff_t)i * pair_stride, row_stride, pair_stride, width, height,
+                                         d_flow + (size_t)i * width * height * 2, pyr_scale, levels, winsize, iterations,
+                                         poly_n, poly_sigma, flags);
+                if (rc) return rc;
+            }
+            return NSOF_OK;
+        }
+    }
+
     nsof_poly_taps ptaps;
     if ((rc = nsof_host_poly_taps(poly_n, poly_sigma, &ptaps))) return nsof_set_error(ctx, rc, "poly taps");
     const int L = nsof_farneback_effective_levels(width, height, pyr_scale, levels);

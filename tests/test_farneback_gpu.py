@@ -495,3 +495,37 @@ def test_recip_matches_ieee_division(ctx, torch_dev):
         ctx.synchronize()
         assert torch.equal(fast.view(torch.int64), ieee.view(torch.int64)), f"rep {rep}"
         assert torch.equal(ieee, 1.0 / x)
+
+
+@pytest.mark.gpu
+def test_batches_larger_than_memory_are_chunked(nsof_lib, ctx, torch_dev, monkeypatch):
+    """A batch whose workspace would not fit the device is run in chunks of as many pairs as fit (here capped by hand
+    with NSOF_MAX_PAIRS): same result as the unchunked call, pairs and consecutive-frame sequences, default and exact
+    order."""
+    import torch
+    from nsof import _lib, synth
+    h, w, n = 96, 160, 7
+    base, _ = synth.make_pair(19, h + 40, w + 40)
+    frames = np.stack([np.ascontiguousarray(base[5 + 2 * i:5 + 2 * i + h, 3 * i:3 * i + w]) for i in range(n + 1)])
+    d = _dev(torch_dev, frames)
+    P = nsof_lib.FarnebackParams(*A)
+    for exact in (0, 1):
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, exact)
+        try:
+            res = {}
+            for cap in (None, "3", "1"):
+                if cap is None:
+                    monkeypatch.delenv("NSOF_MAX_PAIRS", raising=False)
+                else:
+                    monkeypatch.setenv("NSOF_MAX_PAIRS", cap)
+                seq = torch.empty((n, h, w, 2), dtype=torch.float32, device=torch_dev)
+                par = torch.empty_like(seq)
+                nsof_lib.farneback_sequence(d, seq, n + 1, h, w, P, ctx=ctx)
+                nsof_lib.farneback_batch(d[:-1], d[1:], par, n, h, w, P, ctx=ctx)
+                ctx.synchronize()
+                res[cap] = (seq.cpu().numpy(), par.cpu().numpy())
+            for cap in ("3", "1"):
+                assert np.array_equal(res[cap][0], res[None][0]) and np.array_equal(res[cap][1], res[None][1]), (exact, cap)
+            assert np.array_equal(res[None][0], res[None][1])
+        finally:
+            ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
