@@ -555,8 +555,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     }
 
     {
-        // A batch whose workspace (116 B/px/pair: level images, expansions, second flow buffer; + matrices / column sums
-        // in the unfused / exact forms) would not fit the device's free memory is run in chunks of as many pairs as do
+        // A batch whose workspace (56 B/px/pair = 116 MB per 1080p pair: level images, expansions, second flow buffer;
+        // + 20 / 40 B/px of matrices / column sums in the unfused / exact forms) would not fit the device's free memory is run in chunks of as many pairs as do
         // fit -- same kernels on sub-ranges of the same buffers, so the result does not depend on the chunking.
         // NSOF_MAX_PAIRS caps the chunk by hand (tests).
         const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact ? 40 : 0)) + 4096;
