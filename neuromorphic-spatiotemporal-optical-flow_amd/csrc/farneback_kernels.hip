@@ -1512,6 +1512,8 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
     // segment the height so that the grid has >= ~2048 blocks, but keep segments >= 64 rows
     int segs = 1;
     while (segs < 64 && (long long)strips * n_img * segs < 2048 && (H / (segs * 2)) >= 64) segs *= 2;
+    // a lone pair: segments down to 16 rows (each re-loads 2N+1 rows of warm-up) until there is a workgroup per CU
+    while (segs < 128 && (long long)strips * n_img * segs < 256 && (H / (segs * 2)) >= 16) segs *= 2;
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
@@ -1585,6 +1587,17 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
             const int U = S == 2 ? 2 : 3;
             int seg_rows = S == 2 ? 32 : (S == 4 ? 24 : 15);
             seg_rows = (seg_rows + U - 1) / U * U;
+            {
+                // few images (one call per camera frame): shorter segments so that the launch still has ~1000 waves;
+                // a segment re-runs ~KS+1 source rows of warm-up, which only matters when the GPU is full anyway
+                const long waves_x = (W / CWL + 63) / 64;
+                const long have = waves_x * ((hk + seg_rows - 1) / seg_rows) * n_img;
+                if (have < 1024) {
+                    const long want_seg = (1024 + waves_x * n_img - 1) / (waves_x * n_img);
+                    const int rows = (int)std::max<long>(U, (hk / want_seg) / U * U);
+                    if (rows < seg_rows) seg_rows = rows;
+                }
+            }
             const int nseg = (hk + seg_rows - 1) / seg_rows;
             dim3 grid((W / CWL + 63) / 64, (nseg + 3) / 4, n_img);
 #define NSOF_DECIM(SS, KK, CC)                                                                                      \

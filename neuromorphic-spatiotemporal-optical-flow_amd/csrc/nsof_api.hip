@@ -560,9 +560,12 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         // fit -- same kernels on sub-ranges of the same buffers, so the result does not depend on the chunking.
         // NSOF_MAX_PAIRS caps the chunk by hand (tests).
         const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact ? 40 : 0)) + 4096;
-        size_t free_b = 0, total_b = 0;
-        NSOF_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-        size_t fit = (size_t)((double)(free_b + ctx->ws_bytes) * 0.92) / per_pair;
+        size_t fit = ctx->ws_bytes / per_pair;   // what the workspace already holds needs no query (lone calls stay cheap)
+        if ((size_t)n_pairs > fit) {
+            size_t free_b = 0, total_b = 0;
+            NSOF_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+            fit = (size_t)((double)(free_b + ctx->ws_bytes) * 0.92) / per_pair;
+        }
         if (const char* e = getenv("NSOF_MAX_PAIRS")) {
             const long v = atol(e);
             if (v >= 1 && (size_t)v < fit) fit = (size_t)v;
