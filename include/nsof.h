@@ -65,10 +65,11 @@ int nsof_synchronize(nsof_ctx* ctx);
 /* NSOF_OPT_ROW_BANDS (default 0): for SMALL batches (one call per camera frame, the reference's own call pattern).  The
  * fused iteration kernel walks an image strip top to bottom in one workgroup, because the library's column sums are one
  * running sum from row 0; a lone 1080p pair then occupies 8 of 256 compute units.  1 = split every strip into row bands
- * (automatic height), >= 4 = bands of that many rows: each band starts its column sums with a direct sum of its first
- * window, which differs from the running sum in the last bits -- the same class of deviation as the row-sum order
- * above (DESIGN.md section 2 gives the measured end-point difference).  Off by default so that a pair's flow does not
- * depend on the batch it was part of.  Environment default: NSOF_ROW_BANDS. */
+ * (automatic height; applied from winsize 9 up), >= 4 = bands of that many rows at any window: each band starts its
+ * column sums with a direct sum of its first window, which lacks the rounding history of the running sum -- the same
+ * class of deviation as the row-sum order above but more frequent: ~1e-5 on textured frames with wide windows, 4th
+ * decimal at many pixels with 3x3 / 4x4 windows (DESIGN.md section 5.1 has the soak counts).  Off by default so that a
+ * pair's flow does not depend on the batch it was part of.  Environment default: NSOF_ROW_BANDS. */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);

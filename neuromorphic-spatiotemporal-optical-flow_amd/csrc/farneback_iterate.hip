@@ -1242,10 +1242,15 @@ int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R
     // Opt-in row bands (NSOF_OPT_ROW_BANDS): a small batch has too few (strip, pair) workgroups for 256 CUs and each
     // walks the whole height; bands of rows add workgroups at the price of 2m+1 extra rows per band.  1 = automatic
     // (bands no shorter than 32 rows, until the launch has about two workgroups per CU), >= 4 = that many rows.
+    // Automatic mode only from winsize 9 up: with small windows the 2x2 systems are rank deficient often enough that a
+    // band's restart shows in the 4th decimal of many pixels (parity soak); an explicit row
+    // count is taken at its word.
     int band_rows = 0;
     if (ctx->opt_row_bands > 0) {
         if (ctx->opt_row_bands >= 4) {
             band_rows = (ctx->opt_row_bands + 3) & ~3;
+        } else if (winsize < 9) {
+            band_rows = 0;
         } else {
             const int want = (512 + (int)(grid.x * grid.z) - 1) / (int)(grid.x * grid.z);   // bands per strip
             band_rows = std::max(32, ((H + want - 1) / want + 3) & ~3);

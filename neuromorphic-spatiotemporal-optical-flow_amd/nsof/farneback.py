@@ -62,8 +62,9 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     (``NSOF_OPT_EXACT_ROWSUMS``: bit-identical to the CPU restatement on any input, about half the throughput),
     False = the default per-pixel sums, None = whatever the context / ``install(exact=...)`` says.
     ``low_latency`` (keyword only): True = row bands in the iteration kernel for this call (``NSOF_OPT_ROW_BANDS``:
-    a lone 1080p call drops from 4.1 to 1.4 ms; column sums restart per band, so the flow moves in its 5th decimal,
-    more where the 2x2 system is rank deficient); ignored together with ``exact=True``."""
+    a lone 1080p call drops from 3.7 to 1.1 ms; column sums restart per band, so the flow moves in its 5th decimal,
+    more where the 2x2 system is rank deficient -- the automatic mode therefore applies from winsize 9 up); ignored
+    together with ``exact=True``."""
     prev = _as_gray_u8(prev, "prev")
     next = _as_gray_u8(next, "next")  # noqa: A001
     if prev.shape != next.shape:

@@ -42,6 +42,8 @@ def main():
     worst = (0.0, None)
     t0 = time.time()
     kinds = {"generic": 0, "pow2_aligned": 0, "reference_sets": 0, "low_texture": 0}
+    above_by_kind = {k: 0 for k in kinds}          # cases above 1e-4, by kind and by window size class
+    above_by_window = {"winsize<=5": [0, 0], "6..10": [0, 0], ">=11": [0, 0]}   # [above 1e-4, cases]
     for case in range(a.cases):
         kind = ("generic", "pow2_aligned", "reference_sets", "low_texture")[case % 4]
         if kind == "pow2_aligned":     # sizes that take the exact-decimation pyramid kernels
@@ -80,6 +82,11 @@ def main():
         exact += int(err == 0.0)
         for key, th in (("1e-5", 1e-5), ("1e-4", 1e-4), ("1e-3", 1e-3)):
             above[key] += int(err > th)
+        wkey = "winsize<=5" if p[2] <= 5 else ("6..10" if p[2] <= 10 else ">=11")
+        above_by_window[wkey][1] += 1
+        if err > 1e-4:
+            above_by_kind[kind] += 1
+            above_by_window[wkey][0] += 1
         if err > worst_abs[0]:
             worst_abs = (err, {"case": case, "kind": kind, "shape": [h, w], "params": list(p),
                                "pixels_above_1e-4": int((np.abs(got - want).max(-1) > 1e-4).sum())})
@@ -87,7 +94,9 @@ def main():
             worst = (rel, {"case": case, "shape": [h, w], "params": list(p), "abs": err,
                            "max_flow": float(np.abs(want).max())})
     print(json.dumps({"mode": a.mode, "cases": a.cases, "seed": a.seed, "kinds": kinds, "bit_identical": exact,
-                      "cases_with_max_abs_above": above, "worst_abs_error": worst_abs[0], "worst_abs_case": worst_abs[1],
+                      "cases_with_max_abs_above": above, "above_1e-4_by_kind": above_by_kind,
+                      "above_1e-4_by_window_[above,cases]": above_by_window,
+                      "row_bands": int(os.environ.get("NSOF_ROW_BANDS", "0") or 0), "worst_abs_error": worst_abs[0], "worst_abs_case": worst_abs[1],
                       "worst_relative_error": worst[0], "worst_case": worst[1],
                       "seconds": round(time.time() - t0, 1)}))
 

@@ -434,14 +434,15 @@ def test_row_bands_mode_is_opt_in_and_close(ctx, nsof_lib, oracle):
     cut into row bands whose column sums start from a direct sum instead of the library's running sum from row 0 --
     same numbers to ~1e-16, hence a flow that stays inside the oracle tolerance on textured frames (params A, wide
     window) and moves in the 4th decimal where 3x3 windows are rank deficient (params B; same sensitivity as the
-    row-sum order).  Ragged last bands, bands shorter than the window, and images shorter than
-    one band (no split: bit-identical to the default) are covered."""
+    row-sum order; which is why the automatic mode leaves windows below 9 alone: value 1 with
+    params B is bit-identical to the default).  Ragged last bands, bands shorter than the window, and images shorter
+    than one band (no split: bit-identical to the default) are covered."""
     from nsof import _lib, synth
     assert ctx.get_option(_lib.OPT_ROW_BANDS) == 0
     assert ctx._lib.nsof_set_option(ctx.ptr, _lib.OPT_ROW_BANDS, -1) == _lib.NSOF_EINVAL
     ns = 1e-4   # the north-star tolerance (max-abs end-point error)
     cases = [((1080, 1920), A, 1, ns), ((203, 317), A, 32, ns), ((203, 317), A, 4, ns),
-             ((135, 240), Cc, 8, 1e-3), ((801, 801), B, 1, 1e-3), ((30, 200), A, 32, 0.0)]
+             ((135, 240), Cc, 8, 1e-3), ((801, 801), B, 32, 1e-3), ((801, 801), B, 1, 0.0), ((30, 200), A, 32, 0.0)]
     for (h, w), params, bands, tol in cases:
         prev, nxt = synth.make_pair(4242 + h, h, w)
         base = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
