@@ -248,7 +248,8 @@ def main():
                                                   ent["traffic_over_algorithmic"])
                         out[key]["traffic_source"] = ("estimated: algorithmic bytes x PMC ratio "
                                                       f"{ent['traffic_over_algorithmic']} from profiles/hbm_traffic.json "
-                                                      "(rocprofv3 --pmc pass of scripts/stage_bench.py, see its _doc)")
+                                                      "(rocprofv3 --pmc passes over this bench's own launches, all "
+                                                      "levels: scripts/prof_traffic_bench.sh, see its _doc)")
         if world == 1 and prof and args.mode == "pairs" and not args.no_fast_leg:
             out.update(fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of=roof,
                                         prof=prof, steps=max(2, min(args.steps, 5))))
