@@ -142,6 +142,12 @@ def main():
     from nsof import _lib
     from nsof.farneback import PARAMS_A, PARAMS_B, PARAMS_C
 
+    # NSOF_BENCH_REHEARSAL=1: a dry run of the N > 1 code path on a box with fewer GPUs than ranks -- the ranks share
+    # the devices that exist and the two collectives (barrier, max of the elapsed time) run over gloo on host tensors.
+    # Its numbers mean nothing (the ranks time-share one GPU); real runs use one GPU per rank and RCCL.
+    rehearsal = os.environ.get("NSOF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torch.distributed.run: always RCCL
@@ -149,7 +155,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     p = {"A": PARAMS_A, "B": PARAMS_B, "C": PARAMS_C}[args.params]
     h, w, n = args.height, args.width, args.pairs
@@ -187,7 +196,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -229,6 +238,8 @@ def main():
                        "mode": args.mode, "pairs_per_gpu_per_step": n, "global_pairs_per_step": n * world,
                        "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
         }
+        if rehearsal:
+            out["rehearsal"] = "NSOF_BENCH_REHEARSAL=1: ranks share the GPUs present, gloo collectives -- not a measurement"
         if io_rec:
             out["io_gather"] = io_rec
         if prof:

@@ -52,3 +52,22 @@ def test_bench_json_contract():
     sc = d["single_call"]
     assert sc["default"]["host_to_host_ms"] > 0 and sc["row_bands"]["device_resident_ms"] > 0
     assert sc["row_bands"]["max_abs_vs_default"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_path_rehearsal():
+    """The N > 1 code path of bench.py as the driver launches it (torch.distributed.run, one process per rank), on a
+    box with one GPU: NSOF_BENCH_REHEARSAL=1 lets the two ranks share the device and run the barrier / max-over-ranks
+    over gloo.  Checks the plumbing (rank 0 prints exactly one line, whole-job value, ranks exit cleanly), not speed."""
+    env = dict(os.environ, NSOF_SKIP_BUILD="1", NSOF_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pairs", "8"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_pairs_per_step"] == 16 and d["scaling"] == "weak"
+    assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
+    assert "rehearsal" in d and "cpu_baseline" not in d     # rank-0-only legs run at N = 1 only
