@@ -44,14 +44,22 @@ def synth_pairs_gpu(torch, dev, n, h, w, seed0):
     nexts = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
     r = 9
     k = torch.exp(-torch.arange(-r, r + 1, device=dev, dtype=torch.float32) ** 2 / (2 * 3.0 * 3.0))
-    k = (k / k.sum())
+    kt = (k / k.sum()).tolist()
     ys, xs = torch.meshgrid(torch.arange(h, device=dev, dtype=torch.float32),
                             torch.arange(w, device=dev, dtype=torch.float32), indexing="ij")
     for i in range(n):
         g.manual_seed(seed0 + i)
         base = torch.rand((1, 1, h + 2 * pad, w + 2 * pad), generator=g, device=dev)
-        base = F.conv2d(F.pad(base, (r, r, 0, 0), mode="reflect"), k.view(1, 1, 1, -1))
-        base = F.conv2d(F.pad(base, (0, 0, r, r), mode="reflect"), k.view(1, 1, -1, 1))
+        # separable Gaussian as explicit tap sums (plain elementwise kernels: no MIOpen find / user database, which
+        # eight ranks starting at once would all hit, and the same bits on every rank and box)
+        padded = F.pad(base, (r, r, 0, 0), mode="reflect")
+        acc = torch.zeros_like(base)
+        for j in range(2 * r + 1):
+            acc.add_(padded[..., j:j + base.shape[-1]], alpha=float(kt[j]))
+        padded = F.pad(acc, (0, 0, r, r), mode="reflect")
+        base = torch.zeros_like(acc)
+        for j in range(2 * r + 1):
+            base.add_(padded[..., j:j + acc.shape[-2], :], alpha=float(kt[j]))
         base = (base - base.min()) / (base.max() - base.min()) * 255.0
         u, v = 2.5 + 0.25 * (i % 5), -1.25 - 0.2 * (i % 3)
         th = math.radians(0.2)
