@@ -528,8 +528,6 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     if (!ctx) return NSOF_EINVAL;
     if (sequence) d_next = d_prev;
     if (!d_prev || !d_next || !d_flow || n_pairs < 1) return nsof_set_error(ctx, NSOF_EINVAL, "null buffer or n_pairs<1");
-    if (n_pairs > 32767)   // 2*n_pairs images go on gridDim.z
-        return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "n_pairs=%d exceeds 32767 per call", n_pairs);
     int rc = nsof_check_farneback_params(ctx, width, height, pyr_scale, levels, winsize, iterations, poly_n, flags);
     if (rc) return rc;
     if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
@@ -571,6 +569,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
             if (v >= 1 && (size_t)v < fit) fit = (size_t)v;
         }
         if (fit < 1) fit = 1;
+        if (fit > 32767) fit = 32767;   // 2 * pairs images go on gridDim.z of one launch
         if ((size_t)n_pairs > fit) {
             for (int i = 0; i < n_pairs; i += (int)fit) {
                 const int nb = n_pairs - i < (int)fit ? n_pairs - i : (int)fit;

@@ -530,3 +530,21 @@ def test_batches_larger_than_memory_are_chunked(nsof_lib, ctx, torch_dev, monkey
             assert np.array_equal(res[None][0], res[None][1])
         finally:
             ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
+
+
+@pytest.mark.gpu
+def test_more_pairs_than_one_grid_holds(nsof_lib, ctx, torch_dev):
+    """40 000 small pairs in ONE call (a launch addresses at most 32767 pairs through gridDim.z; the driver chunks):
+    spot-checked against single calls."""
+    import torch
+    n, h, w = 40000, 24, 40
+    g = torch.Generator(device=torch_dev).manual_seed(9)
+    frames = torch.randint(0, 256, (n + 1, h, w), dtype=torch.uint8, device=torch_dev, generator=g)
+    flow = torch.empty((n, h, w, 2), dtype=torch.float32, device=torch_dev)
+    P = nsof_lib.FarnebackParams(0.5, 2, 5, 2, 5, 1.1, 0)
+    nsof_lib.farneback_batch(frames[:-1], frames[1:], flow, n, h, w, P, ctx=ctx)
+    ctx.synchronize()
+    host = frames.cpu().numpy()
+    for i in (0, 1, 32766, 32767, 32768, n - 1):
+        one = nsof_lib.calcOpticalFlowFarneback(host[i], host[i + 1], None, *P.as_kwargs().values(), ctx=ctx)
+        assert np.array_equal(flow[i].cpu().numpy(), one), i
