@@ -201,3 +201,46 @@ def simulate_banded(x, y, p, t, sensor_hw, slice_us, simulate_band, dst=0, devic
     if rank != dst:
         return None
     return torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(band_bounds(H, world))], 0).cpu()
+
+
+# ---- sequence end to end: accumulator bands -> surface frames on every rank -> pairs sharded ----
+def events_to_flow_sharded(x, y, p, t, sensor_hw, slice_us, snapshot_every, band_frames, flow_of_frames, device=None):
+    """BASELINE config 5 over several ranks.  Pixels are independent, so the accumulator state is split into row bands
+    (no halo): every rank filters the (replicated, small) event stream to its band and runs
+    ``band_frames(xb, yb, pb, tb, idx_b, (rows, W), snapshot_every, n_frames) -> uint8 [n_frames][rows][W]`` -- the band
+    of every surface frame, on the global slice grid.  The frames are the one real exchange of the pipeline: an
+    all-gather of the bands (``n_frames * H * W`` bytes in total; RCCL under "nccl", host memory under gloo) leaves
+    every rank with the full frames.  Pairs of consecutive frames are independent from then on and are sharded in
+    contiguous chunks: ``flow_of_frames(frames[lo : hi + 1]) -> float32 [hi - lo][H][W][2]`` (on a GPU:
+    ``nsof.farneback_sequence``).  Returns ``((lo, hi), frames, flows_local)``; without an initialised process group
+    it is the single-rank pipeline."""
+    import numpy as np
+    have = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if have else (0, 1)
+    H, W = sensor_hw  # noqa: N806
+    t = np.asarray(t)
+    bounds = np.arange(t[0], t[-1] + slice_us, slice_us)
+    n_frames = (len(bounds) - 1) // snapshot_every
+    if n_frames < 2:
+        raise ValueError("the stream is shorter than two snapshots")
+    y0, y1 = band_bounds(H, world)[rank]
+    xb, yb, pb, tb, _ = events_in_band(x, y, p, t, y0, y1)
+    idx = band_slice_bounds(t, tb, slice_us)
+    dev = collective_device(device)
+    fb = band_frames(xb, yb, pb, tb, idx, (y1 - y0, W), snapshot_every, n_frames)
+    if not torch.is_tensor(fb):
+        fb = torch.as_tensor(np.ascontiguousarray(fb, np.uint8))
+    bands = band_bounds(H, world)
+    if world == 1:
+        frames = fb.to(dev).reshape(n_frames, H, W)
+    else:
+        cap = max(hi - lo for lo, hi in bands)
+        buf = torch.zeros((n_frames, cap, W), dtype=torch.uint8, device=dev)
+        if y1 > y0:
+            buf[:, :y1 - y0] = fb.to(dev).reshape(n_frames, y1 - y0, W)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        frames = torch.cat([parts[r][:, :hi - lo] for r, (lo, hi) in enumerate(bands)], 1).contiguous()
+    lo, hi = shard_bounds(n_frames - 1, world)[rank]
+    flows = flow_of_frames(frames[lo:hi + 1]) if hi > lo else None
+    return (lo, hi), frames, flows

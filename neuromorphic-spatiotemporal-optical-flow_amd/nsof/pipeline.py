@@ -91,6 +91,51 @@ def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, a
     return frames, flows
 
 
+def events_to_flow_sequence_sharded(x, y, p, t, sensor_hw, params=None, slice_us=1000, active_v=-6.0, silent_v=0.0,
+                                    snapshot_every=33, dense=True, ctx=None):
+    """``events_to_flow_sequence`` over the ranks of the current process group (one GPU each): accumulator row bands,
+    all-gather of the 8-bit surface frames, contiguous shards of the frame pairs (``nsof.dist.events_to_flow_sharded``
+    with the GPU accumulator and ``farneback_sequence`` as the two stages).  Returns ``((lo, hi), frames, flows_local)``
+    -- torch CUDA tensors; ``flows_local`` are pairs ``lo .. hi-1`` of the sequence (None for a rank without pairs)."""
+    import torch
+
+    from . import dist as nd
+    from .context import default_context
+    from .farneback import PARAMS_A, farneback_sequence
+    ctx = ctx or default_context()
+    params = params or PARAMS_A
+    H, W = sensor_hw  # noqa: N806
+    dev = torch.device("cuda", ctx.device)
+
+    def band_frames(xb, yb, pb, tb, idx, hw, every, n_frames):
+        rows, w = hw
+        out = torch.empty((n_frames, rows, w), dtype=torch.uint8, device=dev)
+        if rows == 0:
+            return out
+        acc = Accumulator(rows, w, 1, "split", active_v, silent_v, ctx=ctx, dense=dense)
+        try:
+            acc.set_events(xb, yb, pb, tb, idx)
+            for k in range(n_frames):
+                acc.run(k * every, every)
+                acc.surface_u8(out[k])
+            ctx.synchronize()
+        finally:
+            acc.close()
+        return out
+
+    def flow_of_frames(fr):
+        fr = fr.to(dev).contiguous()
+        flows = torch.empty((fr.shape[0] - 1, H, W, 2), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        farneback_sequence(fr, flows, fr.shape[0], H, W, params, ctx=ctx)
+        ctx.synchronize()
+        return flows
+
+    return nd.events_to_flow_sharded(x, y, p, t, (H, W), slice_us, snapshot_every, band_frames, flow_of_frames, device=dev
+                                     if torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+                                     else None)
+
+
 def gated_flow(gray_map, prev, nxt, cfg, flow_fn=None):
     """Flow of a frame pair restricted to the ROI(s) the gating map selects (``opticalFlow3D`` of the reference)."""
     kw = {} if flow_fn is None else {"flow_fn": flow_fn}

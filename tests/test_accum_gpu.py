@@ -329,6 +329,58 @@ def test_row_bands_with_real_accumulator(nsof_lib, ctx):
             dist.destroy_process_group()
 
 
+def test_sharded_sequence_pipeline_equals_single_gpu(nsof_lib, ctx):
+    """events -> accumulator row bands -> all-gather of the surface frames -> sharded frame pairs
+    (nsof.pipeline.events_to_flow_sequence_sharded) on an RCCL process group of one rank: same
+    frames and flows as the single-GPU pipeline; and with the stream cut into two bands by hand (what two ranks would
+    compute) the stitched frames are the same bytes."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+    from nsof import dist as nd
+    from nsof import pipeline, synth
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29910 + os.getpid() % 40)
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("LOCAL_RANK", "0")
+    W, H, every = 192, 135, 4   # noqa: N806
+    x, y, p, t = synth.make_events(23, W, H, 20000, 24_000, box=(40, 30))
+    frames1, flows1 = pipeline.events_to_flow_sequence(x, y, p, t, (H, W), snapshot_every=every, active_v=-6.0,
+                                                       silent_v=0.5, ctx=ctx)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl")
+    try:
+        (lo, hi), frames, flows = pipeline.events_to_flow_sequence_sharded(x, y, p, t, (H, W), snapshot_every=every,
+                                                                            active_v=-6.0, silent_v=0.5, ctx=ctx)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert (lo, hi) == (0, frames1.shape[0] - 1) and frames1.shape[0] >= 4
+    assert torch.equal(frames, frames1) and torch.equal(flows, flows1)
+    assert int(frames1.max()) > int(frames1.min())
+    # two bands by hand, each through the GPU accumulator on the global slice grid
+    n_frames = frames1.shape[0]
+    parts = []
+    for (y0, y1) in nd.band_bounds(H, 2):
+        xb, yb, pb, tb, _ = nd.events_in_band(x, y, p, t, y0, y1)
+        idx = nd.band_slice_bounds(t, tb, 1000)
+        acc = nsof_lib.Accumulator(y1 - y0, W, 1, "split", -6.0, 0.5, ctx=ctx, dense=True)
+        out = torch.empty((n_frames, y1 - y0, W), dtype=torch.uint8, device=frames1.device)
+        try:
+            acc.set_events(xb, yb, pb, tb, idx)
+            for k in range(n_frames):
+                acc.run(k * every, every)
+                acc.surface_u8(out[k])
+            ctx.synchronize()
+        finally:
+            acc.close()
+        parts.append(out)
+    assert torch.equal(torch.cat(parts, 1), frames1)
+
+
 def test_hdf5_event_file_round_trip(nsof_lib, tmp_path):
     """load_events + simulate(h5_path) on a /CD/events file (event_mem_sim.py:69-75, 359-364) and the file set the
     reference writes next to it (:289-322).  h5py lives in the image's conda python only, so the run is a child

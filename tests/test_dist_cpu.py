@@ -112,3 +112,58 @@ def test_accumulator_row_bands_world2():
         p.join(180)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def _seq_worker(rank, world, port, ret):
+    for p_ in (ROOT, PKG):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from nsof import dist as nd
+    from nsof import synth
+    nd.init_from_env("gloo")
+    H, W, every = 37, 52, 5   # noqa: N806  (odd height: bands of 19 and 18 rows)
+    x, y, p, t = synth.make_events(11, W, H, 6000, 48_000, box=(12, 9))
+
+    def band_frames(xb, yb, pb, tb, idx, hw, ev, n_frames):
+        # stand-in for the GPU accumulator: running event count per pixel, one frame every `ev` slices
+        cnt = np.zeros(hw, np.int64)
+        out = np.zeros((n_frames,) + tuple(hw), np.uint8)
+        for s in range(n_frames * ev):
+            np.add.at(cnt, (yb[idx[s]:idx[s + 1]], xb[idx[s]:idx[s + 1]]), 1)
+            if (s + 1) % ev == 0:
+                out[s // ev] = (cnt * 37 % 256).astype(np.uint8)
+        return out
+
+    def flow_of_frames(fr):
+        return _fake_flow(fr[:-1], fr[1:])
+
+    (lo, hi), frames, flows = nd.events_to_flow_sharded(x, y, p, t, (H, W), 1000, every, band_frames, flow_of_frames)
+    from nsof.accumulator import slice_index_array
+    idx = slice_index_array(t, 1000)
+    n_frames = (len(idx) - 1) // every
+    full = torch.as_tensor(band_frames(x, y, p, t, idx, (H, W), every, n_frames))
+    want = _fake_flow(full[:-1], full[1:])
+    ok = torch.equal(frames, full) and (lo, hi) == nd.shard_bounds(n_frames - 1, world)[rank] and hi > lo \
+        and torch.equal(flows, want[lo:hi])
+    ret.put((rank, bool(ok), n_frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_events_to_flow_sharded_world2():
+    """Config 5 over two ranks (third row): accumulator row bands -> all-gather of the surface
+    frames -> contiguous shards of the frame pairs.  Frames on every rank == the unsharded frames, each rank's flows
+    == its slice of the unsharded sequence."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29750 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_seq_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(ret.get(timeout=5) for _ in range(2))
+    assert [g[:2] for g in got] == [(0, True), (1, True)] and got[0][2] >= 4
