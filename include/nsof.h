@@ -254,6 +254,11 @@ int nsof_accum_read_resistance(nsof_accum* acc, int which, float* r_out);
 /* Snapshots taken so far; copy them ([count][H][W] float32) to HOST and clear the ring. */
 int64_t nsof_accum_snapshot_count(const nsof_accum* acc);
 int nsof_accum_read_snapshots(nsof_accum* acc, int which, float* out, int64_t max_count);
+/* Input of the gating image formed on the device: out[H/memsize][W/memsize] (HOST, float64) = the maximum of the device
+ * current v_ds / R over every memsize x memsize block of pixels -- of stored snapshot `snapshot` (0-based, not consumed), or
+ * of the current state when snapshot < 0.  Same values as dividing the downloaded float32 resistance map on the host
+ * (max of v_ds/R = v_ds / min R); only rows x cols doubles cross PCIe instead of the whole surface. */
+int nsof_accum_block_current(nsof_accum* acc, int which, int64_t snapshot, int memsize, double v_ds, double* out);
 /* Frame-driven variant of the same device ODE (simulation/simulationcode_v4_transistor_uav.m:146-227,332-347),
  * float64: imgs = HOST compressed frames [n_frames][H][W] in [0,1]; per frame pair the drive voltage comes
  * from |a-b|*256 through the piecewise map (th1, th2) and modulatefunc, followed by n_sub_steps Euler sub-steps

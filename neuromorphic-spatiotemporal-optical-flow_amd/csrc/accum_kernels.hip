@@ -946,6 +946,48 @@ extern "C" int nsof_accum_read_resistance(nsof_accum* a, int which, float* out)
 
 extern "C" int64_t nsof_accum_snapshot_count(const nsof_accum* a) { return a ? a->snap_count : 0; }
 
+// Block maximum of the device current I = v_ds / R over memsize x memsize pixel blocks: the gating image's input
+// (one value per block) formed on the device instead of from a downloaded surface.
+// max(v_ds / R) = v_ds / min(R) exactly (division by a positive float is monotone), so a block reduces min(R) in
+// float32 -- R from a stored snapshot, or resistance_one(w) of the current state -- and thread 0 divides in double.
+__global__ __launch_bounds__(256) void k_block_min_resistance(const float* __restrict__ src, int is_w, int W, int memsize,
+                                                               int cols, float neg_lam, double v_ds, double* __restrict__ out)
+{
+    __shared__ float part[4];
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const float* base = src + ((size_t)by * memsize) * W + (size_t)bx * memsize;
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < memsize * memsize; i += 256) {
+        const float v = base[(size_t)(i / memsize) * W + (i % memsize)];
+        m = fminf(m, is_w ? resistance_one(v, neg_lam) : v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)by * cols + bx] = v_ds / (double)fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
+}
+
+extern "C" int nsof_accum_block_current(nsof_accum* a, int which, int64_t snapshot, int memsize, double v_ds, double* out)
+{
+    if (!a || !out || which < 0 || which > (a->split ? 1 : 0) || memsize < 1 || memsize > a->W || memsize > a->H || !(v_ds > 0))
+        return NSOF_EINVAL;
+    if (snapshot >= a->snap_count) return nsof_set_error(a->ctx, NSOF_EINVAL, "snapshot %lld of %lld", (long long)snapshot, (long long)a->snap_count);
+    nsof_ctx* ctx = a->ctx;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const int rows = a->H / memsize, cols = a->W / memsize;
+    const size_t bytes = sizeof(double) * rows * cols;
+    int rc = nsof_ws_reserve(ctx, &ctx->tmp, &ctx->tmp_bytes, bytes);
+    if (rc) return rc;
+    const float* src = snapshot < 0 ? a->w[which] : a->snap[which] + (size_t)snapshot * a->npx;
+    hipLaunchKernelGGL(k_block_min_resistance, dim3(cols, rows), dim3(256), 0, ctx->stream, src, snapshot < 0 ? 1 : 0, a->W,
+                       memsize, cols, (float)(-std::log(ROFF / RON)), v_ds, (double*)ctx->tmp);
+    NSOF_HIP(ctx, hipGetLastError());
+    NSOF_HIP(ctx, hipMemcpyAsync(out, ctx->tmp, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NSOF_OK;
+}
+
 extern "C" int nsof_accum_read_snapshots(nsof_accum* a, int which, float* out, int64_t max_count)
 {
     if (!a || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;

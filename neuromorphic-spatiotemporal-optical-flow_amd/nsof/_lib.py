@@ -78,6 +78,7 @@ SIGNATURES = {
     "nsof_accum_read_resistance": (_i, [_vp, _i, _vp]),
     "nsof_accum_snapshot_count": (_i64, [_vp]),
     "nsof_accum_read_snapshots": (_i, [_vp, _i, _vp, _i64]),
+    "nsof_accum_block_current": (_i, [_vp, _i, _i64, _i, _d, _vp]),
     "nsof_accum_frames_f64": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _d, _d, _vp, _vp]),
     "nsof_accum_slice_bounds": (_i64, [_vp, _i64, _i64, _vp, _i64]),
     "nsof_roi_from_surface": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),

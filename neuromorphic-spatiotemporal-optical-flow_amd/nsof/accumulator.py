@@ -196,6 +196,16 @@ class Accumulator:
                                                                self.W if row_stride is None else int(row_stride)),
                        "accum_surface_u8")
 
+    def block_current(self, memsize, which=0, snapshot=-1, v_ds=1.0):
+        """Block maximum of the device current ``v_ds / R`` over ``memsize x memsize`` pixel blocks, float64
+        [H // memsize][W // memsize], reduced on the GPU (``nsof_accum_block_current``): the input of the gating image
+        (``current_to_gray``) without downloading the surface.  ``snapshot`` >= 0 takes a stored snapshot (not
+        consumed), -1 the current state."""
+        out = np.empty((self.H // int(memsize), self.W // int(memsize)), np.float64)
+        self.ctx.check(self.ctx._lib.nsof_accum_block_current(self._p, int(which), int(snapshot), int(memsize),
+                                                              float(v_ds), out.ctypes.data), "accum_block_current")
+        return out
+
     def state(self, which=0):
         """-> dict(w float32 [H][W], next_ok int64 [H][W], slice_counter) -- everything a resume needs."""
         w = np.empty((self.H, self.W), np.float32)
@@ -225,6 +235,9 @@ class Accumulator:
         out = np.empty((self.H, self.W), np.float32)
         self.ctx.check(self.ctx._lib.nsof_accum_read_resistance(self._p, which, out.ctypes.data), "accum_read_R")
         return out
+
+    def snapshot_count(self):
+        return int(self.ctx._lib.nsof_accum_snapshot_count(self._p))
 
     def snapshots(self):
         """-> list (one per array) of float32 [count][H][W]; clears the device ring."""

@@ -31,12 +31,13 @@ def events_to_rois(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slic
     acc = Accumulator(H, W, version, polarity, active_v, silent_v, ctx=ctx)
     try:
         acc.step(x, y, p, t, idx, snap_every=snapshot_every)
-        snaps = acc.snapshots()[0]
+        # block maxima of the current are reduced on the GPU: rows x cols doubles per snapshot cross PCIe, not H x W floats
+        blocks = [acc.block_current(cfg.MEMSIZE, snapshot=k) for k in range(acc.snapshot_count())]
     finally:
         acc.close()
     out = []
-    for r in snaps:
-        g = gating.current_to_gray(surface_to_block_current(r, cfg.MEMSIZE))
+    for cur in blocks:
+        g = gating.current_to_gray(cur)
         tp = np.zeros((H // cfg.MEMSIZE, W // cfg.MEMSIZE))
         tp = gating.update_transition_pic(g, tp, cfg.THRES).astype(np.uint8)
         n, _, stats, _ = gating.connectedComponentsWithStats(tp, cfg.CONNECT)

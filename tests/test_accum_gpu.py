@@ -449,3 +449,32 @@ def test_scheme2_graph_replay_equals_plain_launches(nsof_lib, ctx, monkeypatch, 
             assert np.array_equal(a, b)
         for a, b in zip(res[0][1], res[1][1]):
             assert np.array_equal(a, b)
+
+
+def test_block_current_on_device_equals_host_reduction(nsof_lib, ctx):
+    """nsof_accum_block_current (block maximum of v_ds / R on the GPU, stored snapshots and the current state) == the
+    host reduction over the downloaded float32 resistance maps, bit for bit; block sizes that do not divide the sensor
+    leave the remainder out, as the host version does."""
+    from nsof import pipeline, synth
+    from nsof.accumulator import slice_index_array
+    W, H = 333, 217   # noqa: N806
+    x, y, p, t = synth.make_events(5, W, H, 30000, 60_000, box=(50, 40))
+    idx = slice_index_array(t, 1000)
+    acc = nsof_lib.Accumulator(H, W, 1, "split", -6.0, 0.5, ctx=ctx)
+    try:
+        acc.step(x, y, p, t, idx, snap_every=20)
+        n = acc.snapshot_count()
+        assert n >= 3
+        dev = {ms: [acc.block_current(ms, snapshot=k) for k in range(n)] for ms in (1, 7, 20, 64)}
+        cur = {ms: acc.block_current(ms) for ms in (7, 20)}
+        r_now = acc.resistance()
+        snaps = acc.snapshots()[0]
+    finally:
+        acc.close()
+    for ms, got in dev.items():
+        for k in range(n):
+            want = pipeline.surface_to_block_current(snaps[k], ms)
+            assert got[k].shape == want.shape == (H // ms, W // ms) and np.array_equal(got[k], want), (ms, k)
+    for ms, got in cur.items():
+        assert np.array_equal(got, pipeline.surface_to_block_current(r_now, ms))
+    assert dev[20][-1].max() > dev[20][-1].min()
