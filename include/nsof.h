@@ -323,6 +323,12 @@ int nsof_motion_mask(nsof_ctx* ctx, const float* flow, ptrdiff_t flow_stride_byt
  * remap follows cv2's 8-bit fixed point: map rounded to 1/32 px (half to even), integer part saturated to int16,
  * 15-bit weights, (sum + 2^14) >> 15. */
 enum { NSOF_BORDER_CONSTANT = 0, NSOF_BORDER_REPLICATE = 1 };   /* cv2.BORDER_CONSTANT / cv2.BORDER_REPLICATE */
+/* 8-bit luma of an interleaved 3-channel DEVICE frame as cv2.cvtColor computes it (fixed point, (sum + 2^14) >> 15):
+ * bgr_weights = 0 -> COLOR_RGB2GRAY weights in memory order (what the scripts apply to imread's B,G,R frames,
+ * optical_flow_seg.py:442-443), 1 -> COLOR_BGR2GRAY (:447).  Strides in bytes.  Lets decoded frames stay in HBM up
+ * to the flow call. */
+int nsof_gray_u8_dev(nsof_ctx* ctx, const uint8_t* d_src, ptrdiff_t src_stride, int width, int height, int bgr_weights,
+                     uint8_t* d_dst, ptrdiff_t dst_stride);
 /* cv2.remap for uint8 sources with 1 or 3 interleaved channels and two float32 maps, all on the DEVICE.
  * Strides of the images in bytes, of the maps in floats.  Source up to 32767 x 32767. */
 int nsof_remap_linear_u8_dev(nsof_ctx* ctx, const uint8_t* d_src, ptrdiff_t src_stride, int src_w, int src_h,

@@ -190,6 +190,43 @@ int check_remap_args(nsof_ctx* ctx, int cn, int sw, int sh, ptrdiff_t sstride, i
 
 }  // namespace
 
+// cv2.cvtColor(frame, COLOR_RGB2GRAY / COLOR_BGR2GRAY) for 8-bit frames: (c0*w0 + c1*w1 + c2*w2 + 2^14) >> 15 with the
+// fixed-point weights 9798 / 19235 / 3735 (optical_flow_seg.py:442-447 applies RGB2GRAY to imread's B,G,R frames, so
+// blue takes the red weight; both orders are provided).  A lane converts 4 pixels: 12 source bytes -> one dword.
+__global__ __launch_bounds__(256) void k_gray_u8(const uint8_t* __restrict__ src, ptrdiff_t src_stride, int W, int H, int w0,
+                                                  int w1, int w2, uint8_t* __restrict__ dst, ptrdiff_t dst_stride)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const uint8_t* s = src + (ptrdiff_t)y * src_stride + 3 * (ptrdiff_t)x;
+    uint8_t* d = dst + (ptrdiff_t)y * dst_stride + x;
+    const int n = min(4, W - x);
+    unsigned packed = 0;
+    for (int i = 0; i < n; i++) {
+        const unsigned g = ((unsigned)s[3 * i] * w0 + (unsigned)s[3 * i + 1] * w1 + (unsigned)s[3 * i + 2] * w2 + (1u << 14)) >> 15;
+        packed |= g << (8 * i);
+    }
+    if (n == 4 && (reinterpret_cast<uintptr_t>(d) & 3) == 0) {
+        *reinterpret_cast<unsigned*>(d) = packed;
+    } else {
+        for (int i = 0; i < n; i++) d[i] = (uint8_t)(packed >> (8 * i));
+    }
+}
+
+extern "C" int nsof_gray_u8_dev(nsof_ctx* ctx, const uint8_t* d_src, ptrdiff_t src_stride, int width, int height, int bgr_weights,
+                                uint8_t* d_dst, ptrdiff_t dst_stride)
+{
+    if (!ctx || !d_src || !d_dst || width < 1 || height < 1 || src_stride < 3 * (ptrdiff_t)width || dst_stride < width)
+        return NSOF_EINVAL;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    nsof_prof_scope ps(ctx, NSOF_K_REMAP);
+    const int w0 = bgr_weights ? 3735 : 9798, w2 = bgr_weights ? 9798 : 3735;
+    hipLaunchKernelGGL(k_gray_u8, dim3((width + 1023) / 1024, height), dim3(256), 0, ctx->stream, d_src, src_stride, width, height,
+                       w0, 19235, w2, d_dst, dst_stride);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
 extern "C" int nsof_remap_linear_u8_dev(nsof_ctx* ctx, const uint8_t* d_src, ptrdiff_t src_stride, int src_w, int src_h,
                                         int channels, const float* d_map_x, ptrdiff_t map_x_stride_floats,
                                         const float* d_map_y, ptrdiff_t map_y_stride_floats, int dst_w, int dst_h,

@@ -25,8 +25,8 @@ from .gating import (GatingConfig, connectedComponentsWithStats, current_to_gray
                      gating_maps, load_gating_stack, opticalFlow3D, process_merged_region, process_separate_regions, update_transition_pic)
 from .segment import (MORPH_CROSS, MORPH_ELLIPSE, MORPH_RECT, dilate, erode, getStructuringElement, motion_mask,  # noqa: F401,E402
                       motion_mask_dev, process_flow_region, task_results)
-from .predict import (BORDER_CONSTANT, BORDER_REPLICATE, INTER_LINEAR, calculateIntegralError, predict_region,  # noqa: F401,E402
-                      predict_region_dev, remap, structural_similarity)
+from .predict import (BORDER_CONSTANT, BORDER_REPLICATE, INTER_LINEAR, calculateIntegralError, gray_u8_dev,  # noqa: F401,E402
+                      predict_region, predict_region_dev, remap, structural_similarity)
 from .frames import compress_image, crop_image, im2double, imresize_lanczos3, process_images  # noqa: F401,E402
 from .flowviz import flow_to_image, flow_uv_to_colors, make_colorwheel, viz  # noqa: F401,E402
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "nsof_morph_binary_u8_dev": (_i, [_vp, _i, _vp, _pd, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _pd]),
     "nsof_motion_mask_dev": (_i, [_vp, _vp, _pd, _i, _i, _d, _i, _i, _vp, _pd]),
     "nsof_motion_mask": (_i, [_vp, _vp, _pd, _i, _i, _d, _i, _i, _vp, _pd]),
+    "nsof_gray_u8_dev": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd]),
     "nsof_remap_linear_u8_dev": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd, _vp, _pd, _i, _i, _i, _i, _vp, _pd]),
     "nsof_predict_warp_u8_dev": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd, _i, _i, _i, _i, _i, _i, _vp, _pd]),
     "nsof_predict_warp_u8": (_i, [_vp, _vp, _pd, _i, _i, _i, _vp, _pd, _i, _i, _i, _i, _i, _i, _vp, _pd]),

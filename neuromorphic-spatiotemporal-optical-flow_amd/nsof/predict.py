@@ -22,6 +22,23 @@ INTER_LINEAR = 1                         # cv2.INTER_LINEAR
 BORDER_CONSTANT, BORDER_REPLICATE = 0, 1  # cv2.BORDER_*
 
 
+def gray_u8_dev(d_frame, d_gray, code="RGB2GRAY", *, ctx=None):
+    """``cv2.cvtColor(frame, COLOR_RGB2GRAY | COLOR_BGR2GRAY)`` on DEVICE memory: ``d_frame`` uint8 [H][W][3] torch CUDA
+    tensor (rows may be strided), ``d_gray`` uint8 [H][W].  Same bytes as ``nsof.gating.frame_to_gray``; asynchronous on
+    the context's stream -- decoded frames need not visit the host before the flow call."""
+    ctx = ctx or default_context()
+    if code not in ("RGB2GRAY", "BGR2GRAY"):
+        raise NsofValueError("gray_u8_dev: code must be RGB2GRAY or BGR2GRAY", _lib.NSOF_EINVAL)
+    h, w = int(d_frame.shape[0]), int(d_frame.shape[1])
+    if tuple(d_frame.shape) != (h, w, 3) or tuple(d_gray.shape) != (h, w) or d_frame.stride(2) != 1 or d_frame.stride(1) != 3 \
+            or d_gray.stride(1) != 1:
+        raise NsofValueError("gray_u8_dev: uint8 [H][W][3] interleaved frame and [H][W] output expected", _lib.NSOF_ESHAPE)
+    rc = ctx._lib.nsof_gray_u8_dev(ctx.ptr, dev_ptr(d_frame), int(d_frame.stride(0)), w, h, 1 if code == "BGR2GRAY" else 0,
+                                   dev_ptr(d_gray), int(d_gray.stride(0)))
+    ctx.check(rc, "gray_u8_dev")
+    return d_gray
+
+
 def remap(src, map1, map2, interpolation=INTER_LINEAR, dst=None, borderMode=BORDER_CONSTANT, borderValue=0,  # noqa: N803
           *, ctx=None):
     """``cv2.remap`` for uint8 images (1 or 3 channels), two float32 maps and INTER_LINEAR."""
