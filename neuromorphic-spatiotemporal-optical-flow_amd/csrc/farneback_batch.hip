@@ -173,7 +173,9 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
 
         // workspace: level images, expansions, two flow buffers (every level uses their leading part)
         const size_t szI = align_up(maxI * 4, 256), szR = align_up(maxR * 4, 256), szF = align_up(maxF * 8, 256);
-        const size_t szV = exact ? szR : 0;   // exact order: column sums, 5 doubles per pixel = the expansion's footprint
+        static const bool exact_2k = [] { const char* e = getenv("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
+        const bool exact_x = exact && !exact_2k;   // one fused kernel (k_iterate_x); 2k: column sums through HBM
+        const size_t szV = exact && !exact_x ? szR : 0;   // two-kernel exact order: column sums, 5 doubles per pixel = the expansion's footprint
         if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + 2 * szF + szV))) return rc;
         char* base = (char*)ctx->ws;
         float* dI = (float*)base;
@@ -200,7 +202,10 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
             if ((rc = nsof_launch_polyexp_het(ctx, nk_items, dt, max_w[k], max_h[k], ptaps, dI, dR))) return rc;
             for (int it = 0; it < p.iterations; it++) {
                 const bool final = k == 0 && it == p.iterations - 1;
-                if (exact)
+                if (exact_x)
+                    rc = nsof_launch_iterate_x_het(ctx, nk_items, dt, max_w[k], max_h[k], dR, szR / 4, fb[cur], fb[cur ^ 1], final,
+                                                   p.winsize);
+                else if (exact)
                     rc = nsof_launch_iterate_het_exact(ctx, nk_items, dt, max_w[k], max_h[k], dR, fb[cur], fb[cur ^ 1], final,
                                                        p.winsize, dV);
                 else

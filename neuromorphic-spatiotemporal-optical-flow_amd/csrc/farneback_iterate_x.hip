@@ -1,0 +1,715 @@
+// Farneback inner iteration, fused, with the box filter's ROW sums in the reference library's own order.
+//
+// Reference arithmetic: FarnebackUpdateMatrices + FarnebackUpdateFlow_Blur of the library behind
+// cv2.calcOpticalFlowFarneback (/root/reference/optical_flow_seg.py:203).  The library forms the row sums of the
+// (2m+1)^2 box as ONE running double-precision sum along each image row,
+//     g += vsum[x+m] - vsum[x-m-1]        (started from vsum[0]*(m+2) + vsum[1] + .. + vsum[m-1]),
+// and where the 2x2 system of a pixel is rank deficient (straight edges, flat areas) the rounding history of that sum
+// decides the 4th decimal of the flow: summing each pixel's window directly (k_iterate_q, farneback_iterate.hip) leaves
+// 1e-4 on the reference's real autodriving frames.  The running sum is sequential along the WHOLE row, across every
+// column strip.  This kernel keeps it inside the strip walker:
+//
+//   * a workgroup owns a strip of SW = 192 output columns (+ 2m+1 halo columns: a ring of 208 columns) of one pair and
+//     walks it top to bottom, four rows per step, like k_iterate_q: producer waves compute the rows of M into a ring in
+//     LDS (per ring entry one float4 + one float: planes 0..3 move with one 16-byte LDS access);
+//   * consumer waves, thread <-> OUTPUT column x, keep the running column sums of the two columns x+m and x-m-1 in
+//     registers (the column sums of every column are formed twice: once as a window's entering and once as its
+//     leaving column -- no exchange between threads) and publish D[x] = vsum[x+m] - vsum[x-m-1] of the step's four
+//     rows to LDS;
+//   * ONE scanner wave, lane <-> (row, plane) of the step, runs the library's recurrence g += D[x] over the strip's
+//     columns, in place (g[x] takes D[x]'s slot);  the consumers then solve their column's four 2x2 systems;
+//   * the strips of one image are chained left to right: a strip's scanner starts each row from the value its left
+//     neighbour's scanner ended on (20 doubles per step), handed over through global memory as data-tagged 8-byte
+//     granules {tag = launch epoch, 32 bits of payload} -- relaxed agent-scope stores and loads, no fences, no flags --
+//     by a producer wave with time to spare (the scanner only sees LDS).  Strip s is therefore always a step or so
+//     behind strip s-1; nothing else couples them.
+//   * a workgroup takes its (pair, strip) job from a per-XCD ticket counter at start-up, in strip order, so the left
+//     neighbour of a running strip is itself running or done whatever order the hardware dispatches workgroups in
+//     (no assumption on dispatch order or placement; an XCD owning whole pairs is for L2 locality only).
+//
+// D / g are double-buffered, so within one step (ONE workgroup barrier) the scanner runs step t while the consumers solve
+// step t-1 out of the other buffer and then form and publish the column sums of step t+1 into it, and the producers
+// write the rows of step t+2.  The scanner is bound by instruction issue (a dependent v_add_f64 every ~10 clocks, ~12 per
+// 16-byte LDS load, ~30 per 16-byte LDS store: scripts/scan_probe.hip), about 31 clocks per column: it is the longest
+// role of a step and nothing else may sit on its critical path.  Arithmetic and its order are the library's, bit for bit.
+// HBM traffic per pixel per iteration: 56 B as k_iterate_q (+ 80 B per strip boundary and row of carries).
+#include "iterate_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+// XCD (0..7) this wave runs on: HW_REG_XCC_ID (id 20), bits 3:0.
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
+
+// Geometry: 11 waves.  Waves 0-2 consumers (192 output columns), wave 3 the scanner, waves 4-6 / 8-10 producers of rows
+// 0,1 / 2,3 of every step for ring columns 0..191 (thread <-> column), wave 7 the producer of all four rows for ring columns
+// 192..207 (lane <-> (row, column)): half the work of the others, and the wave that shares SIMD 3 with the scanner (waves
+// go to SIMD wave % 4), whose chain would otherwise starve a full producer wave there -- or be starved by it.
+// 154 VGPRs (3 waves per SIMD), 160 KB of LDS: ring 2m+9 rows x 208 x 20 B, D / g 2 x 31 KB.  (A 4th consumer wave for 240 of
+// 256 columns makes 4 waves on one SIMD: 128 VGPRs, ~190 spilled registers, 1.6x slower; and no room for the second buffer.)
+template <int MH>
+struct XGeom {
+    static constexpr int COLS = 208, NCW = 3, RB = 4;
+    static constexpr int RL = 2 * MH + 1 + 2 * RB;          // ring rows: the 2m+5 a step reads and the 4 being written
+    static constexpr int HALO = 2 * MH + 1;                 // ring column of output j's entering column: j + HALO
+    static constexpr int SW = NCW * 64;                     // output columns per strip
+    static_assert(SW + HALO <= COLS && SW % 8 == 0, "strip geometry");
+    static constexpr int NB = COLS / 64, REM = COLS % 64;   // full 64-column producer blocks, columns of the remainder wave
+    static_assert(REM == 16, "the remainder wave maps 4 rows x 16 columns onto its 64 lanes");
+    static constexpr int SVW = SW + 2;                      // doubles per (row, plane) of D / g (even: 16-byte rows)
+    static constexpr int WAVES = NCW + 1 + 2 * NB + 1;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr size_t SV1_BYTES = sizeof(double) * 4 * 5 * SVW;      // one buffer of D / g
+    static constexpr size_t SV_BYTES = 2 * SV1_BYTES;
+    static constexpr size_t VI_BYTES = sizeof(double) * 2 * 4 * 5 * MH;     // row-start column sums (strip 0), 2 buffers
+    static constexpr size_t JOB_BYTES = 16;
+    static constexpr size_t CB_BYTES = sizeof(double) * 2 * 2 * 20;         // row-end / row-start sums between scanner and I/O wave
+    static constexpr size_t RING4_BYTES = sizeof(float) * 4 * RL * COLS, RING1_BYTES = sizeof(float) * RL * COLS;
+    static constexpr size_t SMEM = SV_BYTES + VI_BYTES + JOB_BYTES + CB_BYTES + RING4_BYTES + RING1_BYTES;
+};
+
+// The ring of M rows: entry (slot, column) = planes 0..3 as one float4 + plane 4.
+struct XRing {
+    float4* q;
+    float* c;
+    int cols;
+    __device__ __forceinline__ void put(int slot, int col, const float (&M)[5]) const
+    {
+        q[slot * cols + col] = make_float4(M[0], M[1], M[2], M[3]);
+        c[slot * cols + col] = M[4];
+    }
+    __device__ __forceinline__ void get(int slot, int col, float (&M)[5]) const
+    {
+        const float4 v = q[slot * cols + col];
+        M[0] = v.x; M[1] = v.y; M[2] = v.z; M[3] = v.w;
+        M[4] = c[slot * cols + col];
+    }
+};
+
+#ifdef NSOF_X_TIMING
+// Tuning build only (scripts/build_variant.sh xt farneback_iterate_x.hip -DNSOF_X_TIMING): constant-clock time that one wave
+// of each role of the workgroup with job (pair 0, strip 1) spends in each part of a step; read by scripts/x_timing.py.
+__device__ unsigned long long g_xt[32];
+#define XT_DECL(on_)                                                        \
+    const bool xt_on = (on_);                                               \
+    unsigned long long xt_acc[4] = {0, 0, 0, 0}, xt_prev = __builtin_amdgcn_s_memtime()
+#define XT_MARK(slot)                                                       \
+    do {                                                                    \
+        const unsigned long long xt_now = __builtin_amdgcn_s_memtime();     \
+        xt_acc[(slot) & 3] += xt_now - xt_prev;                             \
+        xt_prev = xt_now;                                                   \
+    } while (0)
+#define XT_FLUSH(base)                                                      \
+    do {                                                                    \
+        if (xt_on)                                                          \
+            for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_xt[(base) + k_], xt_acc[k_]); \
+    } while (0)
+extern "C" int nsof_debug_xtiming(unsigned long long* out32, int reset)
+{
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_xt), sizeof(g_xt)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_xt), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define XT_DECL(on_)
+#define XT_MARK(slot)
+#define XT_FLUSH(base)
+#endif
+
+constexpr unsigned X_SPIN_LIMIT = 1u << 21;   // polls of a carry before giving up (seconds): the grid always drains
+
+// ---- producers ------------------------------------------------------------------------------------------------------
+// One row of M: consume the loads issued two steps ago, write the ring, issue the same row of step + 2 (i + 8) and fetch
+// its flow for step + 4 (i + 16).  i = stream index = image row (clamped at the bottom).
+template <int MH>
+__device__ __forceinline__ void x_produce(RowIn& in, FlowSrc<false>::Raw& fl, const XRing& ring, const Planes& R0,
+                                          const Planes& R1, const FlowSrc<false>& F, int W, int H, int xc, int col, int i)
+{
+    constexpr int RL = XGeom<MH>::RL;
+    float Mn[5];
+    matrix_from(in, xc, min(i, H - 1), W, H, Mn);
+    ring.put((i + MH + 1) % RL, col, Mn);
+    issue_row(in, R0, R1, W, H, xc, min(i + 8, H - 1), F.resolve(fl));
+    fl = F.fetch(min(i + 16, H - 1));
+}
+
+// rows 0..m-1 of the window of image row 0 for this thread's column; the m+1 rows above the image replicate row 0.
+// ring slot of stream index i is (i + m + 1) % RL.
+template <int MH>
+__device__ __forceinline__ void x_rows_above(const XRing& ring, const Planes& R0, const Planes& R1, const FlowSrc<false>& F,
+                                             int W, int H, int xc, int col)
+{
+    RowIn t;
+    float M0[5];
+    issue_row(t, R0, R1, W, H, xc, 0, F.at(0));
+    matrix_from(t, xc, 0, W, H, M0);
+#pragma unroll
+    for (int j = 0; j <= MH + 1; j++) ring.put(j, col, M0);   // stream indices -m-1 .. 0
+#pragma unroll
+    for (int i = 1; i < MH; i++) {
+        float Mi[5];
+        const int r = min(i, H - 1);
+        issue_row(t, R0, R1, W, H, xc, r, F.at(r));
+        matrix_from(t, xc, r, W, H, Mi);
+        ring.put(i + MH + 1, col, Mi);
+    }
+}
+
+// Barriers (all roles alike): Ba, Bb, then B(t) for t = 0 .. nimg-1.
+//   before Ba       step 0 (and the rows above the image)
+//   Ba .. Bb        step 1                  (consumers: column sums of step 0 -> D(0))
+//   Bb .. B(0)      step 2                  (consumers: column sums of step 1; scanner: step 0)
+//   B(t-1) .. B(t)  step t+2                (consumers: solve t-1, column sums of t+1; scanner: step t)
+// A ring of 2m+9 rows holds exactly the rows the consumers read in a step (2m+5) and the four being written.
+// Full producer wave: thread <-> ring column, rows 2 GP, 2 GP + 1 of every step.
+template <int MH, int GP>
+__device__ __forceinline__ void x_producer_loop(const XRing& ring, const Planes& R0, const Planes& R1,
+                                                const FlowSrc<false>& F, int W, int H, int xc, int col, int nimg, bool xt)
+{
+    if constexpr (GP == 0) x_rows_above<MH>(ring, R0, R1, F, W, H, xc, col);
+    RowIn in[2][2];
+    FlowSrc<false>::Raw fl[2][2];
+#pragma unroll
+    for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = min(4 * ts + MH + 2 * GP + rr, H - 1);
+            issue_row(in[ts][rr], R0, R1, W, H, xc, r, F.at(r));
+        }
+#pragma unroll
+    for (int ts = 0; ts < 2; ts++)
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) fl[ts][rr] = F.fetch(min(4 * (ts + 2) + MH + 2 * GP + rr, H - 1));
+    auto step = [&](auto tsc, int t) {
+        constexpr int TS = decltype(tsc)::value;
+        x_produce<MH>(in[TS][0], fl[TS][0], ring, R0, R1, F, W, H, xc, col, 4 * t + MH + 2 * GP);
+        x_produce<MH>(in[TS][1], fl[TS][1], ring, R0, R1, F, W, H, xc, col, 4 * t + MH + 2 * GP + 1);
+    };
+    step(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();                                                                 // Ba
+    step(std::integral_constant<int, 1>{}, 1);
+    XT_DECL(xt && (threadIdx.x & 63) == 0);
+    __syncthreads();                                                                 // Bb
+    for (int t = 0; t < nimg; t += 2) {
+        XT_MARK(1);                                                                  // wait at the barrier
+        step(std::integral_constant<int, 0>{}, t + 2);
+        XT_MARK(0);                                                                  // rows
+        __syncthreads();                                                             // B(t)
+        if (t + 1 >= nimg) break;
+        XT_MARK(1);
+        step(std::integral_constant<int, 1>{}, t + 3);
+        XT_MARK(0);
+        __syncthreads();                                                             // B(t+1)
+    }
+    XT_FLUSH(8 + 8 * GP);
+}
+
+// Remainder wave: lane <-> (row r of the step, ring column 192 + c): one row per step and thread.  With time to spare, it
+// is also the strip's I/O wave: it publishes the row-end sums the scanner left in LDS (cb[0][step & 1][20]) to the right
+// neighbour and fetches the left neighbour's (-> cb[1][step & 1][20], a step ahead of the scanner), so that the scanner
+// itself never touches global memory: the carries move as data-tagged 8-byte granules {tag = launch epoch, 32 bits of
+// payload} with relaxed agent-scope stores and loads -- no fences, no flags.
+// A strip settles about a step plus the hand-off latency behind its left neighbour and then never waits (a fetch that
+// finds a stale tag is repeated, which delays this strip's barrier: the lag only grows until the fetches succeed).
+template <int MH>
+__device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, const Planes& R0, const Planes& R1,
+                                                 const FlowSrc<false>& F, int W, int H, int xc, int col, int r, int nimg,
+                                                 gu64* cin, gu64* cout, unsigned epoch, gu32* err, bool xt)
+{
+    const int lane = threadIdx.x & 63;
+    const bool io = lane < 20;
+    const int l = io ? lane : 0;
+    // the left neighbour's row-end sums of step s -> cb[1][s & 1]: the loads are issued first (fetch_issue), this thread's
+    // row is produced meanwhile, then the tags are checked (fetch_finish; a stale tag means the neighbour is not a full step
+    // ahead yet: poll)
+    unsigned long long g0 = 0, g1 = 0;
+    auto fetch_issue = [&](int s) {
+        if (!cin || !io) return;
+        g0 = __hip_atomic_load(cin + 40 * s + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g1 = __hip_atomic_load(cin + 40 * s + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto fetch_finish = [&](int s) {
+        if (!cin || !io) return;
+        for (unsigned spins = 0;; spins++) {
+            if (__all((unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch)) break;
+            if (spins > X_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            g0 = __hip_atomic_load(cin + 40 * s + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g1 = __hip_atomic_load(cin + 40 * s + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cb[40 + (s & 1) * 20 + l] = __hiloint2double((int)(unsigned)g1, (int)(unsigned)g0);
+    };
+    // the scanner's row-end sums of step s (cb[0][s & 1]) -> the right neighbour
+    auto publish = [&](int s) {
+        if (!cout || !io) return;
+        const double S = cb[(s & 1) * 20 + l];
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        __hip_atomic_store(cout + 40 * s + 2 * l, tag | (unsigned)__double2loint(S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cout + 40 * s + 2 * l + 1, tag | (unsigned)__double2hiint(S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (r == 0) x_rows_above<MH>(ring, R0, R1, F, W, H, xc, col);
+    RowIn in[2];
+    FlowSrc<false>::Raw fl[2];
+#pragma unroll
+    for (int ts = 0; ts < 2; ts++) {
+        const int y = min(4 * ts + MH + r, H - 1);
+        issue_row(in[ts], R0, R1, W, H, xc, y, F.at(y));
+    }
+#pragma unroll
+    for (int ts = 0; ts < 2; ts++) fl[ts] = F.fetch(min(4 * (ts + 2) + MH + r, H - 1));
+    x_produce<MH>(in[0], fl[0], ring, R0, R1, F, W, H, xc, col, MH + r);
+    __syncthreads();                                                                 // Ba
+    fetch_issue(0);
+    x_produce<MH>(in[1], fl[1], ring, R0, R1, F, W, H, xc, col, 4 + MH + r);
+    fetch_finish(0);
+    XT_DECL(xt && lane == 0);
+    __syncthreads();                                                                 // Bb
+    for (int t = 0; t < nimg; t += 2) {
+        XT_MARK(1);
+        if (t >= 1) publish(t - 1);
+        if (t + 1 < nimg) fetch_issue(t + 1);
+        x_produce<MH>(in[0], fl[0], ring, R0, R1, F, W, H, xc, col, 4 * (t + 2) + MH + r);
+        XT_MARK(0);
+        if (t + 1 < nimg) fetch_finish(t + 1);
+        XT_MARK(2);
+        __syncthreads();                                                             // B(t)
+        if (t + 1 >= nimg) break;
+        XT_MARK(1);
+        publish(t);
+        if (t + 2 < nimg) fetch_issue(t + 2);
+        x_produce<MH>(in[1], fl[1], ring, R0, R1, F, W, H, xc, col, 4 * (t + 3) + MH + r);
+        XT_MARK(0);
+        if (t + 2 < nimg) fetch_finish(t + 2);
+        XT_MARK(2);
+        __syncthreads();                                                             // B(t+1)
+    }
+    publish(nimg - 1);
+    XT_FLUSH(12);
+}
+
+// ---- consumers: thread <-> output column j of the strip ----------------------------------------------------------
+template <int MH>
+__device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, double* vinit, float2* Fout, size_t fpitch,
+                                                int W, int H, int x0, int j, int nimg, double scale, bool strip0, bool xt)
+{
+    using G = XGeom<MH>;
+    constexpr int RL = G::RL, SVW = G::SVW, HALO = G::HALO;
+    const int rb = j, ra = j + HALO;   // ring columns of the leaving (x-m-1) and entering (x+m) image column
+    // row-start sums of strip 0 (the library's "g = vsum[0]*(m+2) + vsum[1] + .. + vsum[m-1]"): vsum[0] is the leaving
+    // column of output 0, vsum[k] that of output k + m + 1
+    const int vik = j == 0 ? 0 : j - MH - 1;
+    const bool vi_thread = strip0 && (j == 0 || (j >= MH + 2 && j <= 2 * MH));
+    __syncthreads();   // Ba: the rows above the image and step 0 are in the ring
+    double va[5], vb[5];
+    {
+        float a0[5], b0[5];
+        ring.get(MH + 1, ra, a0);
+        ring.get(MH + 1, rb, b0);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            va[c] = (double)(a0[c] * (float)(MH + 2));   // float product, as "srow0[x]*(m+2)"
+            vb[c] = (double)(b0[c] * (float)(MH + 2));
+        }
+#pragma unroll
+        for (int i = 1; i < MH; i++) {
+            ring.get(i + MH + 1, ra, a0);
+            ring.get(i + MH + 1, rb, b0);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                va[c] += (double)a0[c];
+                vb[c] += (double)b0[c];
+            }
+        }
+    }
+    int slot_new = (2 * MH + 1) % RL;           // stream index m    -> slot 2m+1
+    int slot_old = 0;                           // stream index -m-1 -> slot 0
+    const int x = x0 + j;
+    XT_DECL(xt && j == 0);
+    // step s: four more rows enter the windows of this thread's two columns; D of the step goes to buffer s & 1
+    auto column_sums = [&](int s) {
+        double* svj = sv + (s & 1) * (G::SV1_BYTES / sizeof(double)) + j;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float na[5], oa[5], nb[5], ob[5];
+            ring.get(slot_new, ra, na);
+            ring.get(slot_old, ra, oa);
+            ring.get(slot_new, rb, nb);
+            ring.get(slot_old, rb, ob);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float da = na[c] - oa[c];
+                const float db = nb[c] - ob[c];
+                va[c] += (double)da;
+                vb[c] += (double)db;
+                svj[(q * 5 + c) * SVW] = va[c] - vb[c];
+            }
+            if (vi_thread) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) vinit[(((s & 1) * 4 + q) * 5 + c) * MH + vik] = vb[c];
+            }
+            slot_new = slot_new + 1 == RL ? 0 : slot_new + 1;
+            slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
+        }
+    };
+    column_sums(0);
+    __syncthreads();   // Bb: D(0) is published, step 1 is in the ring
+    for (int t = 0; t <= nimg; t++) {
+        XT_MARK(1);        // wait at the barrier
+        if (t >= 1 && x < W) {   // solve step t-1: the scanner left g in buffer (t-1) & 1
+            const double* svj = sv + ((t - 1) & 1) * (G::SV1_BYTES / sizeof(double)) + j;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int yo = 4 * (t - 1) + q;
+                const double g11 = svj[(q * 5 + 0) * SVW] * scale, g12 = svj[(q * 5 + 1) * SVW] * scale;
+                const double g22 = svj[(q * 5 + 2) * SVW] * scale;
+                const double h1 = svj[(q * 5 + 3) * SVW] * scale, h2 = svj[(q * 5 + 4) * SVW] * scale;
+                const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
+                const float ox = (float)((g11 * h2 - g12 * h1) * idet), oy = (float)((g22 * h1 - g12 * h2) * idet);
+                if (yo < H) nsof_store_stream2(reinterpret_cast<float*>(Fout + (size_t)yo * fpitch + x), ox, oy);
+            }
+        }
+        XT_MARK(2);        // solve
+        if (t == nimg) break;
+        // D(t+1) takes the slots this thread has just read (same buffer, own column)
+        if (t + 1 < nimg) column_sums(t + 1);
+        XT_MARK(0);        // column sums
+        __syncthreads();   // B(t): scan of step t done, D(t+1) published, step t+2 in the ring
+    }
+    XT_FLUSH(0);
+}
+
+// ---- the scanner wave: lane l = q * 5 + c <-> (row q, plane c) of the step -------------------------------------------
+template <int MH>
+__device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, double* cb, bool has_left, int nimg, int ncols,
+                                               int lane, bool xt)
+{
+    using G = XGeom<MH>;
+    constexpr int SVW = G::SVW;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const bool act = lane < 20;
+    const int l = act ? lane : 0;
+    __syncthreads();   // Ba
+    __builtin_amdgcn_s_setprio(3);   // the one dependent chain every other wave of the step ends up waiting for
+    __syncthreads();   // Bb
+    XT_DECL(xt && lane == 0);
+    for (int t = 1; t <= nimg; t++) {   // iteration t scans step t-1
+        XT_MARK(6);    // wait at the barrier
+        d2* row = reinterpret_cast<d2*>(sv + ((t - 1) & 1) * (G::SV1_BYTES / sizeof(double)) + l * SVW);
+        if (act) {
+            double S;
+            if (has_left) {
+                S = cb[40 + ((t - 1) & 1) * 20 + l];   // fetched by the I/O wave a step ago
+            } else {
+                const double* vi = vinit + (((t - 1) & 1) * 20 + l) * MH;
+                S = vi[0] * (double)(MH + 2);
+#pragma unroll
+                for (int k = 1; k < MH; k++) S += vi[k];
+            }
+            // The library's recurrence over the strip's columns, in place, hand-scheduled: blocks of 8 columns in two
+            // register sets (v64-79 / v80-95) used alternately; a block's four 16-byte loads are issued one block ahead and
+            // its four stores behind its adds; a set's last register pair carries the running sum into the other set's first
+            // add, so a set is reloaded only after that add has issued.  Before a block's adds the queue then holds [its
+            // loads, the previous block's stores(, the next block's loads)] and lgkmcnt(7 / 10..8) waits for exactly its own
+            // loads (LDS operations of a wave complete in order).  The compiler's own schedule of this loop waited for
+            // every store (its loop-header wait is the merge of two different queue states).  Reads past the strip's last
+            // block land in the spare doubles / the next row and are not used.
+            {
+                unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)row;
+                int nrem = (ncols >> 3) - 1;   // blocks after the first
+                asm volatile(
+                "ds_read_b128 v[64:67], %[a]\n\t"
+                "ds_read_b128 v[68:71], %[a] offset:16\n\t"
+                "ds_read_b128 v[72:75], %[a] offset:32\n\t"
+                "ds_read_b128 v[76:79], %[a] offset:48\n\t"
+                "ds_read_b128 v[80:83], %[a] offset:64\n\t"
+                "ds_read_b128 v[84:87], %[a] offset:80\n\t"
+                "ds_read_b128 v[88:91], %[a] offset:96\n\t"
+                "ds_read_b128 v[92:95], %[a] offset:112\n\t"
+                "s_waitcnt lgkmcnt(7)\n\t"
+                "v_add_f64 v[64:65], %[S], v[64:65]\n\t"
+                "v_add_f64 v[66:67], v[66:67], v[64:65]\n\t"
+                "s_waitcnt lgkmcnt(6)\n\t"
+                "v_add_f64 v[68:69], v[66:67], v[68:69]\n\t"
+                "v_add_f64 v[70:71], v[70:71], v[68:69]\n\t"
+                "s_waitcnt lgkmcnt(5)\n\t"
+                "v_add_f64 v[72:73], v[70:71], v[72:73]\n\t"
+                "v_add_f64 v[74:75], v[74:75], v[72:73]\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_f64 v[76:77], v[74:75], v[76:77]\n\t"
+                "v_add_f64 v[78:79], v[78:79], v[76:77]\n\t"
+                "s_nop 1\n\t"
+                "ds_write_b128 %[a], v[64:67]\n\t"
+                "ds_write_b128 %[a], v[68:71] offset:16\n\t"
+                "ds_write_b128 %[a], v[72:75] offset:32\n\t"
+                "ds_write_b128 %[a], v[76:79] offset:48\n\t"
+                "s_cmp_lt_i32 %[n], 2\n\t"
+                "s_cbranch_scc1 .Lxs_tail%=\n"
+                ".Lxs_loop%=:\n\t"
+                "s_waitcnt lgkmcnt(7)\n\t"
+                "v_add_f64 v[80:81], v[78:79], v[80:81]\n\t"
+                "ds_read_b128 v[64:67], %[a] offset:128\n\t"
+                "ds_read_b128 v[68:71], %[a] offset:144\n\t"
+                "ds_read_b128 v[72:75], %[a] offset:160\n\t"
+                "ds_read_b128 v[76:79], %[a] offset:176\n\t"
+                "v_add_f64 v[82:83], v[82:83], v[80:81]\n\t"
+                "s_waitcnt lgkmcnt(10)\n\t"
+                "v_add_f64 v[84:85], v[82:83], v[84:85]\n\t"
+                "v_add_f64 v[86:87], v[86:87], v[84:85]\n\t"
+                "s_waitcnt lgkmcnt(9)\n\t"
+                "v_add_f64 v[88:89], v[86:87], v[88:89]\n\t"
+                "v_add_f64 v[90:91], v[90:91], v[88:89]\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "v_add_f64 v[92:93], v[90:91], v[92:93]\n\t"
+                "v_add_f64 v[94:95], v[94:95], v[92:93]\n\t"
+                "s_nop 1\n\t"
+                "ds_write_b128 %[a], v[80:83] offset:64\n\t"
+                "ds_write_b128 %[a], v[84:87] offset:80\n\t"
+                "ds_write_b128 %[a], v[88:91] offset:96\n\t"
+                "ds_write_b128 %[a], v[92:95] offset:112\n\t"
+                "s_waitcnt lgkmcnt(7)\n\t"
+                "v_add_f64 v[64:65], v[94:95], v[64:65]\n\t"
+                "ds_read_b128 v[80:83], %[a] offset:192\n\t"
+                "ds_read_b128 v[84:87], %[a] offset:208\n\t"
+                "ds_read_b128 v[88:91], %[a] offset:224\n\t"
+                "ds_read_b128 v[92:95], %[a] offset:240\n\t"
+                "v_add_f64 v[66:67], v[66:67], v[64:65]\n\t"
+                "s_waitcnt lgkmcnt(10)\n\t"
+                "v_add_f64 v[68:69], v[66:67], v[68:69]\n\t"
+                "v_add_f64 v[70:71], v[70:71], v[68:69]\n\t"
+                "s_waitcnt lgkmcnt(9)\n\t"
+                "v_add_f64 v[72:73], v[70:71], v[72:73]\n\t"
+                "v_add_f64 v[74:75], v[74:75], v[72:73]\n\t"
+                "s_waitcnt lgkmcnt(8)\n\t"
+                "v_add_f64 v[76:77], v[74:75], v[76:77]\n\t"
+                "v_add_f64 v[78:79], v[78:79], v[76:77]\n\t"
+                "s_nop 1\n\t"
+                "ds_write_b128 %[a], v[64:67] offset:128\n\t"
+                "ds_write_b128 %[a], v[68:71] offset:144\n\t"
+                "ds_write_b128 %[a], v[72:75] offset:160\n\t"
+                "ds_write_b128 %[a], v[76:79] offset:176\n\t"
+                "v_add_u32 %[a], 128, %[a]\n\t"
+                "s_sub_i32 %[n], %[n], 2\n\t"
+                "s_cmp_ge_i32 %[n], 2\n\t"
+                "s_cbranch_scc1 .Lxs_loop%=\n"
+                ".Lxs_tail%=:\n\t"
+                "s_cmp_lt_i32 %[n], 1\n\t"
+                "s_cbranch_scc1 .Lxs_done%=\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_f64 v[80:81], v[78:79], v[80:81]\n\t"
+                "v_add_f64 v[82:83], v[82:83], v[80:81]\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_f64 v[84:85], v[82:83], v[84:85]\n\t"
+                "v_add_f64 v[86:87], v[86:87], v[84:85]\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_f64 v[88:89], v[86:87], v[88:89]\n\t"
+                "v_add_f64 v[90:91], v[90:91], v[88:89]\n\t"
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_add_f64 v[92:93], v[90:91], v[92:93]\n\t"
+                "v_add_f64 v[94:95], v[94:95], v[92:93]\n\t"
+                "s_nop 1\n\t"
+                "ds_write_b128 %[a], v[80:83] offset:64\n\t"
+                "ds_write_b128 %[a], v[84:87] offset:80\n\t"
+                "ds_write_b128 %[a], v[88:91] offset:96\n\t"
+                "ds_write_b128 %[a], v[92:95] offset:112\n\t"
+                "v_mov_b64 v[78:79], v[94:95]\n"
+                ".Lxs_done%=:\n\t"
+                "v_mov_b64 %[S], v[78:79]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                    : [S] "+v"(S), [a] "+v"(a), [n] "+s"(nrem)
+                    :
+                    : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+
+            }
+            cb[((t - 1) & 1) * 20 + l] = S;   // the row-end sums: the I/O wave hands them to the right neighbour
+        }
+        XT_MARK(5);        // scan
+        __syncthreads();   // B(t-1): g of step t-1 is complete
+    }
+    XT_FLUSH(4);
+}
+
+// tickets: 8 counters, 32 words apart.  carry: granules, see the launcher.  n: pairs (items with HET); nstrips: strips of
+// the widest image of the launch.
+template <int MH, bool HET>
+__global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
+    const float* __restrict__ R0b, const float* __restrict__ R1b, size_t pair_stride, const float* __restrict__ flow_in,
+    float* __restrict__ flow_out, int W, int H, int block_size, const nsof_het_item* __restrict__ items, int het_final,
+    int n, int nstrips, unsigned long long* carry, unsigned* tickets, unsigned epoch, unsigned* err)
+{
+    using G = XGeom<MH>;
+    constexpr int SW = G::SW, COLS = G::COLS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
+    double* sv = reinterpret_cast<double*>(smem_x);                                                 // [2][4 rows][5][SVW]
+    double* vinit = reinterpret_cast<double*>(smem_x + G::SV_BYTES);                                // [2][4][5][MH]
+    int* job = reinterpret_cast<int*>(smem_x + G::SV_BYTES + G::VI_BYTES);
+    double* cb = reinterpret_cast<double*>(smem_x + G::SV_BYTES + G::VI_BYTES + G::JOB_BYTES);    // [out / in][2][20]
+    XRing ring;
+    ring.q = reinterpret_cast<float4*>(smem_x + G::SV_BYTES + G::VI_BYTES + G::JOB_BYTES + G::CB_BYTES);
+    ring.c = reinterpret_cast<float*>(smem_x + G::SV_BYTES + G::VI_BYTES + G::JOB_BYTES + G::CB_BYTES + G::RING4_BYTES);
+    ring.cols = COLS;
+    const int tid = threadIdx.x;
+    // ---- job: (pair, strip) from this XCD's ticket counter, strips of a pair in order
+    if (tid == 0) {
+        const unsigned share = (unsigned)((n + 7) / 8) * (unsigned)nstrips;
+        unsigned k = xcc_id();
+        unsigned i = __hip_atomic_fetch_add(tickets + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i >= share) {   // more workgroups landed on this XCD than its share: take another XCD's next job
+            for (unsigned d = 1; d < 8 && i >= share; d++) {
+                k = (k + 1) & 7u;
+                i = __hip_atomic_fetch_add(tickets + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        job[0] = i < share ? (int)((i / (unsigned)nstrips) * 8u + k) : -1;
+        job[1] = (int)(i % (unsigned)nstrips);
+    }
+    __syncthreads();
+    const int pair = job[0], strip = job[1];
+    if (pair < 0 || pair >= n) return;   // block-uniform
+    size_t fpitch = (size_t)W;
+    gu64* cbase;
+    if constexpr (HET) {
+        const nsof_het_item& it = items[pair];
+        W = it.wk;
+        H = it.hk;
+        if (strip * SW >= W) return;   // block-uniform, before any further barrier
+        R0b += it.offR;
+        R1b = R0b + 5 * (size_t)W * H;
+        pair_stride = 0;
+        flow_in += 2 * it.offF;
+        cbase = (gu64*)(carry + it.offR / 2);   // an item's carries live in a mirror of its expansion block (always smaller)
+        if (het_final) {
+            flow_out = it.out;
+            fpitch = (size_t)it.out_pitch;
+        } else {
+            flow_out += 2 * it.offF;
+            fpitch = (size_t)W;
+        }
+    } else {
+        if (strip * SW >= W) return;
+        cbase = (gu64*)(carry + (size_t)pair * nstrips * (size_t)(((H + 3) / 4) * 40));
+    }
+    const int nimg = (H + 3) / 4;   // steps of the image
+    const int x0 = strip * SW;
+    const size_t plane = (size_t)W * H;
+    const size_t poff = HET ? 0 : (size_t)pair * pair_stride;
+    const Planes R0 = planes_of(R0b + poff, plane);
+    const Planes R1 = planes_of(R1b + poff, plane);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef NSOF_X_TIMING
+    const bool xt = pair == 0 && strip == 1;
+#else
+    const bool xt = false;
+#endif
+    if (wave < G::NCW) {
+        float2* Fout = reinterpret_cast<float2*>(flow_out) + (HET ? 0 : (size_t)pair * plane);
+        x_consumer_loop<MH>(ring, sv, vinit, Fout, fpitch, W, H, x0, tid, nimg, 1. / (block_size * block_size), strip == 0, xt);
+    } else if (wave == G::NCW) {
+        const int ncols = min(SW, (W - x0 + 7) & ~7);
+        x_scanner_loop<MH>(sv, vinit, cb, strip > 0, nimg, ncols, tid & 63, xt);
+    } else {
+        // producers: waves NCW+1 .. NCW+NB rows 0,1 of blocks 0..NB-1; wave NCW+NB+1 the remainder; then rows 2,3
+        const int pw = wave - (G::NCW + 1);
+        const int lane = tid & 63;
+        FlowSrc<false> F;
+        F.base = reinterpret_cast<const char*>(flow_in) + (HET ? 0 : (size_t)pair * plane * 8);
+        F.W = (unsigned)W;
+        if (pw == G::NB) {
+            const int col = G::NB * 64 + (lane & 15), r = lane >> 4;
+            const int xc = clampi(x0 - MH - 1 + col, 0, W - 1);
+            F.xc = (unsigned)xc;
+            const size_t per_strip = (size_t)nimg * 40;
+            gu64* cin = strip > 0 ? cbase + (size_t)(strip - 1) * per_strip : nullptr;
+            gu64* cout = x0 + SW < W ? cbase + (size_t)strip * per_strip : nullptr;
+            x_remainder_loop<MH>(ring, cb, R0, R1, F, W, H, xc, col, r, nimg, cin, cout, epoch, (gu32*)err, xt);
+        } else {
+            const int blk = pw < G::NB ? pw : pw - G::NB - 1;
+            const int col = blk * 64 + lane;
+            const int xc = clampi(x0 - MH - 1 + col, 0, W - 1);
+            F.xc = (unsigned)xc;
+            if (pw < G::NB)
+                x_producer_loop<MH, 0>(ring, R0, R1, F, W, H, xc, col, nimg, xt && blk == 0);
+            else
+                x_producer_loop<MH, 1>(ring, R0, R1, F, W, H, xc, col, nimg, xt && blk == 0);
+        }
+    }
+}
+
+template <int MH, bool HET>
+int launch_x(nsof_ctx* ctx, int n, int max_w, int max_h, const float* R0, const float* R1, size_t pair_stride,
+             const float* flow_in, float* flow_out, int W, int H, int winsize, const nsof_het_item* items, bool final)
+{
+    using G = XGeom<MH>;
+    if (int rc = lds_opt_in(ctx, k_iterate_x<MH, HET>, G::SMEM)) return rc;
+    const int nstrips = (max_w + G::SW - 1) / G::SW;
+    unsigned long long* carry = nullptr;
+    unsigned* tickets = nullptr;
+    unsigned* err = nullptr;
+    // uniform batches: [pair][strip][row][5] doubles as two granules each; work lists: the mirror of the expansion buffer
+    const size_t cbytes = HET ? 0 : (size_t)n * nstrips * (size_t)((max_h + 3) / 4) * 40 * 8;
+    if (int rc = nsof_xsync_reserve(ctx, cbytes, &carry, &tickets, &err)) return rc;
+    NSOF_HIP(ctx, hipMemsetAsync(tickets, 0, 8 * 32 * sizeof(unsigned), ctx->stream));
+    unsigned epoch = ++ctx->x_epoch;
+    if (epoch == 0) {   // wrapped: every tag in the buffer is stale but may match again -> clear it
+        NSOF_HIP(ctx, hipMemsetAsync(ctx->x_carry, 0, ctx->x_carry_bytes, ctx->stream));
+        epoch = ++ctx->x_epoch;
+    }
+    const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)nstrips;
+    hipLaunchKernelGGL((k_iterate_x<MH, HET>), dim3(grid), dim3(G::THREADS), G::SMEM, ctx->stream, R0, R1, pair_stride, flow_in,
+                       flow_out, W, H, winsize, items, final ? 1 : 0, n, nstrips, carry, tickets, epoch, err);
+    return NSOF_OK;
+}
+
+}  // namespace
+
+bool nsof_iterate_x_supported(int winsize, int W, int H)
+{
+    const int m = winsize / 2;
+    return m >= 1 && m <= 7 && W >= 2 && H >= 2;
+}
+
+#define NSOF_X_SWITCH(HETV, ...)                                                                     \
+    switch (winsize / 2) {                                                                           \
+        case 1: rc = launch_x<1, HETV>(__VA_ARGS__); break;                                          \
+        case 2: rc = launch_x<2, HETV>(__VA_ARGS__); break;                                          \
+        case 3: rc = launch_x<3, HETV>(__VA_ARGS__); break;                                          \
+        case 4: rc = launch_x<4, HETV>(__VA_ARGS__); break;                                          \
+        case 5: rc = launch_x<5, HETV>(__VA_ARGS__); break;                                          \
+        case 6: rc = launch_x<6, HETV>(__VA_ARGS__); break;                                          \
+        case 7: rc = launch_x<7, HETV>(__VA_ARGS__); break;                                          \
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "exact-order fused iteration supports winsize 2..15"); \
+    }
+
+// Exact-order fused iteration (the library's running row sums).  flow_in != flow_out.
+int nsof_launch_iterate_x(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                          const float* flow_in, float* flow_out, int W, int H, int winsize)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    int rc;
+    NSOF_X_SWITCH(false, ctx, n_pairs, W, H, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, nullptr, false)
+    if (rc) return rc;
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// Work-list twin; carries go to ctx's mirror of the level's expansion buffer (R_floats = its size in floats).
+int nsof_launch_iterate_x_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
+                              size_t R_floats, const float* flow_in, float* flow_out, bool final, int winsize)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    unsigned long long* carry;
+    unsigned *tk, *er;
+    if (int rc0 = nsof_xsync_reserve(ctx, R_floats * 4, &carry, &tk, &er)) return rc0;
+    int rc;
+    NSOF_X_SWITCH(true, ctx, n_items, max_w, max_h, R, R, (size_t)0, flow_in, flow_out, 0, 0, winsize, d_items, final)
+    if (rc) return rc;
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}

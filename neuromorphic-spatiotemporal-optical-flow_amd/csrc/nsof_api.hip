@@ -44,6 +44,37 @@ int nsof_ws_reserve(nsof_ctx* ctx, void** buf, size_t* cur, size_t need)
     return NSOF_OK;
 }
 
+int nsof_xsync_reserve(nsof_ctx* ctx, size_t carry_bytes, unsigned long long** carry, unsigned** tickets, unsigned** err)
+{
+    if (!ctx->x_sync) {
+        NSOF_HIP(ctx, hipMalloc((void**)&ctx->x_sync, 2048));
+        NSOF_HIP(ctx, hipMemsetAsync(ctx->x_sync, 0, 2048, ctx->stream));
+    }
+    if (carry_bytes > ctx->x_carry_bytes) {
+        carry_bytes = (carry_bytes + (carry_bytes >> 3) + 4095) & ~(size_t)4095;   // some slack: shapes vary from call to call
+        if (int rc = nsof_ws_reserve(ctx, (void**)&ctx->x_carry, &ctx->x_carry_bytes, carry_bytes)) return rc;
+        NSOF_HIP(ctx, hipMemsetAsync(ctx->x_carry, 0, ctx->x_carry_bytes, ctx->stream));   // tag 0 = never written
+    }
+    *carry = ctx->x_carry;
+    *tickets = ctx->x_sync;
+    *err = ctx->x_sync + 256;
+    ctx->x_dirty = true;
+    return NSOF_OK;
+}
+
+int nsof_xsync_check(nsof_ctx* ctx)
+{
+    if (!ctx->x_dirty || !ctx->x_sync) return NSOF_OK;
+    ctx->x_dirty = false;
+    unsigned w = 0;
+    NSOF_HIP(ctx, hipMemcpy(&w, ctx->x_sync + 256, sizeof(w), hipMemcpyDeviceToHost));
+    if (w) {
+        NSOF_HIP(ctx, hipMemset(ctx->x_sync + 256, 0, sizeof(w)));
+        return nsof_set_error(ctx, NSOF_EDEVICE, "exact-order iteration: a strip's carry never arrived (flags %u); results are invalid", w);
+    }
+    return NSOF_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------
 nsof_prof_scope::nsof_prof_scope(nsof_ctx* c, int k) : ctx(c), id(k), on((c->prof_mask >> k) & 1u)
 {
@@ -206,6 +237,8 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     if (ctx->hstage) hipHostFree(ctx->hstage);
     if (ctx->het_h) hipHostFree(ctx->het_h);
     if (ctx->het_d) hipFree(ctx->het_d);
+    if (ctx->x_carry) hipFree(ctx->x_carry);
+    if (ctx->x_sync) hipFree(ctx->x_sync);
     for (auto ev : ctx->het_ev)
         if (ev) hipEventDestroy(ev);
     nsof_pipe_destroy(ctx);
@@ -266,7 +299,7 @@ extern "C" int nsof_synchronize(nsof_ctx* ctx)
 {
     if (!ctx) return NSOF_EINVAL;
     NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return NSOF_OK;
+    return nsof_xsync_check(ctx);
 }
 
 // ---- filter taps (host, double precision as the reference library computes them) -----------
@@ -492,6 +525,9 @@ extern "C" int nsof_stage_iterate(nsof_ctx* ctx, int n_pairs, const float* d_R, 
         return NSOF_EINVAL;
     if (!nsof_iterate_supported(winsize, width, height)) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "winsize %d not fused", winsize);
     const size_t plane = (size_t)width * height;
+    if (ctx->opt_exact_rowsums && nsof_iterate_x_supported(winsize, width, height))
+        return nsof_launch_iterate_x(ctx, n_pairs, d_R, d_R + 5 * plane, 10 * plane, d_flow_in, d_flow_out, width, height,
+                                     winsize);
     return nsof_launch_iterate(ctx, n_pairs, d_R, d_R + 5 * plane, 10 * plane, d_flow_in, d_flow_out, width, height,
                                winsize);
 }
@@ -533,12 +569,18 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     if (row_stride < width) return nsof_set_error(ctx, NSOF_EINVAL, "row_stride < width");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     const bool exact = ctx->opt_exact_rowsums != 0;
+    // exact row-sum order: ONE fused kernel (k_iterate_x) where the window fits; NSOF_EXACT_IMPL=2k selects the older
+    // two-kernel form (column sums through HBM) for A/B runs
+    static const bool exact_2k = [] { const char* e = getenv("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
+    static const char* fused_env0 = getenv("NSOF_FUSED");
+    const bool exact_x = exact && !exact_2k && !(fused_env0 && fused_env0[0] == '0') && iterations > 0 &&
+                         nsof_iterate_x_supported(winsize, width, height);
     static const int exact_chunk = [] {
         const char* e = getenv("NSOF_EXACT_CHUNK");
         const int v = e ? atoi(e) : 64;
         return v < 1 ? 1 : v;
     }();
-    if (exact && (sequence || n_pairs > exact_chunk)) {
+    if (exact && !exact_x && (sequence || n_pairs > exact_chunk)) {
         // the exact order keeps 40 B/px of column sums (+ 20 B/px of matrices) in HBM: 64 pairs of 1920x1080 at a time
         // (8 GB) fill the GPU -- the row walk has one thread per image row; a sequence is run as its pairs
         const uint8_t* nx = sequence ? d_prev + pair_stride : d_next;
@@ -557,7 +599,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         // + 20 / 40 B/px of matrices / column sums in the unfused / exact forms) would not fit the device's free memory is run in chunks of as many pairs as do
         // fit -- same kernels on sub-ranges of the same buffers, so the result does not depend on the chunking.
         // NSOF_MAX_PAIRS caps the chunk by hand (tests).
-        const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact ? 40 : 0)) + 4096;
+        const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact && !exact_x ? 40 : 0)) + 4096;
         size_t fit = ctx->ws_bytes / per_pair;   // what the workspace already holds needs no query (lone calls stay cheap)
         if ((size_t)n_pairs > fit) {
             size_t free_b = 0, total_b = 0;
@@ -595,12 +637,12 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // NSOF_FUSED=0 forces the unfused pair (A/B runs; measured slower even for a lone 1080p pair: 6.1 vs 4.0 ms).
     static const char* fused_env = getenv("NSOF_FUSED");
     // exact row-sum order: the fused two-kernel form (phase A + row scan) where the window fits, else the unfused kernels
-    const bool exact_fused = exact && nsof_iterate_exact_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0');
+    const bool exact_fused = exact && (exact_x || (nsof_iterate_exact_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0')));
     const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0') &&
                        (!exact || exact_fused);
     const size_t szI = align_up(n_img * n0 * 4, 256), szR = align_up(n_img * 5 * n0 * 4, 256);
     const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
-    const size_t szV = exact ? align_up(B * 5 * n0 * 8, 256) : 0;   // transposed column sums of the exact order
+    const size_t szV = exact && !exact_x ? align_up(B * 5 * n0 * 8, 256) : 0;   // column sums of the two-kernel exact order
     if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM + szV))) return rc;
     char* base = (char*)ctx->ws;   // (re-derived below if the level overlap grows the workspace)
     float* dI = (float*)base;
@@ -749,6 +791,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
                 if (it == 0 && pending_ups)
                     rc = nsof_launch_iterate_upsample(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], pw, ph,
                                                       (float)(1. / pyr_scale), fb[cur ^ 1], wk, hk, winsize);
+                else if (exact_x)
+                    rc = nsof_launch_iterate_x(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize);
                 else if (exact_fused)
                     rc = nsof_launch_iterate_exact(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize, dV);
                 else

@@ -53,6 +53,14 @@ struct nsof_ctx {
     // level, flow resample) that share the CUs with the LDS-bound iteration / expansion kernels, and its events
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ov_events;
+    // exact-order fused iteration (farneback_iterate_x.hip): strip-to-strip carries (tagged granules, zeroed when
+    // allocated, never again: a launch's tag is its epoch), the per-XCD ticket counters + timeout word (x_sync:
+    // tickets at word 0, timeout word at word 256), the launch epoch, and whether a launch's timeout word needs a look
+    unsigned long long* x_carry = nullptr;
+    size_t x_carry_bytes = 0;
+    unsigned* x_sync = nullptr;
+    unsigned x_epoch = 0;
+    bool x_dirty = false;
 };
 
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
@@ -162,6 +170,16 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
 bool nsof_iterate_exact_supported(int winsize, int W, int H);
 int nsof_launch_iterate_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                               const float* flow_in, float* flow_out, int W, int H, int winsize, double* vsum);
+// Exact-order fused iteration in ONE kernel (running row sums inside the strip walker, strips chained by carries).
+bool nsof_iterate_x_supported(int winsize, int W, int H);
+int nsof_launch_iterate_x(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                          const float* flow_in, float* flow_out, int W, int H, int winsize);
+int nsof_launch_iterate_x_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
+                              size_t R_floats, const float* flow_in, float* flow_out, bool final, int winsize);
+// Carry buffer of at least `carry_bytes` (0: whatever exists) + ticket / timeout words of that kernel.
+int nsof_xsync_reserve(nsof_ctx* ctx, size_t carry_bytes, unsigned long long** carry, unsigned** tickets, unsigned** err);
+// Reads the timeout word of the exact-order kernel after the stream has drained; NSOF_EDEVICE if a carry never arrived.
+int nsof_xsync_check(nsof_ctx* ctx);
 bool nsof_iterate_upsample_supported(int winsize, int W, int H);
 // First iteration of a level: flow_in = resample(coarse_flow [sh][sw][2]) * mul, computed on the fly.
 int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
