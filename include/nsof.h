@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NSOF_ABI_VERSION 1
+#define NSOF_ABI_VERSION 2   /* 2: NSOF_OPT_EXACT_ROWSUMS defaults to 1; option ranges validated */
 
 typedef enum nsof_status {
     NSOF_OK = 0,
@@ -57,19 +57,24 @@ int nsof_synchronize(nsof_ctx* ctx);
  * from the default (exact) path by the end-point error DESIGN.md reports.  Applies to the uniform-shape entry points;
  * the work-list entries always run the exact kernel.  New contexts take the default from the environment
  * variable NSOF_POLYEXP_F32. */
-/* NSOF_OPT_EXACT_ROWSUMS (default 0): 1 = the box-filter row sums are formed as the reference library forms them, one
- * running double-precision sum along each image row, instead of per pixel -- the only place where the default path
- * leaves the library's operation order.  Same numbers to ~1e-16; where the 2x2 system is rank deficient (real footage,
- * small windows) that decides the flow's 4th decimal, and this mode then equals a CPU restatement of the library bit for bit (about
- * half the throughput: the column sums pass through HBM between two kernels).  Environment default: NSOF_EXACT_ROWSUMS. */
-/* NSOF_OPT_ROW_BANDS (default 0): for SMALL batches (one call per camera frame, the reference's own call pattern).  The
+/* NSOF_OPT_EXACT_ROWSUMS (default 1): the box-filter row sums are formed as the reference library forms them, ONE
+ * running double-precision sum along each image row (g += vsum[x+m] - vsum[x-m-1]), inside the fused iteration kernel:
+ * every stage then keeps the library's operation order and the flow equals a CPU restatement of the library bit for bit
+ * on any input (windows up to 15: one kernel per iteration; larger windows: the unfused kernels, same results).
+ * 0 = the "fast row sums" mode: each pixel's window is summed directly -- the same numbers to ~1e-16, a few per cent
+ * faster; where the 2x2 system is rank deficient (straight edges and flat areas of real footage, small windows) the
+ * rounding history decides the flow's 4th decimal and this mode leaves the library by up to ~8e-4.
+ * Environment default: NSOF_EXACT_ROWSUMS. */
+/* NSOF_OPT_ROW_BANDS (default 0; applies to the fast row-sum mode only, NSOF_OPT_EXACT_ROWSUMS = 0): for SMALL batches
+ * (one call per camera frame, the reference's own call pattern).  The
  * fused iteration kernel walks an image strip top to bottom in one workgroup, because the library's column sums are one
  * running sum from row 0; a lone 1080p pair then occupies 8 of 256 compute units.  1 = split every strip into row bands
  * (automatic height; applied from winsize 9 up), >= 4 = bands of that many rows at any window: each band starts its
  * column sums with a direct sum of its first window, which lacks the rounding history of the running sum -- the same
  * class of deviation as the row-sum order above but more frequent: ~1e-5 on textured frames with wide windows, 4th
  * decimal at many pixels with 3x3 / 4x4 windows (DESIGN.md section 5.1 has the soak counts).  Off by default so that a
- * pair's flow does not depend on the batch it was part of.  Environment default: NSOF_ROW_BANDS. */
+ * pair's flow does not depend on the batch it was part of.  Values 2 and 3 are rejected.  Environment default:
+ * NSOF_ROW_BANDS. */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);

@@ -58,6 +58,8 @@ struct XGeom {
     static_assert(SW + HALO <= COLS && SW % 8 == 0, "strip geometry");
     static constexpr int NB = COLS / 64, REM = COLS % 64;   // full 64-column producer blocks, columns of the remainder wave
     static_assert(REM == 16, "the remainder wave maps 4 rows x 16 columns onto its 64 lanes");
+    static constexpr int SEG = SW / 2;                      // the strip's two scan segments (see x_scanner_loop)
+    static_assert(SEG % 8 == 0, "a segment is a whole number of 8-column blocks");
     static constexpr int SVW = SW + 2;                      // doubles per (row, plane) of D / g (even: 16-byte rows)
     static constexpr int WAVES = NCW + 1 + 2 * NB + 1;
     static constexpr int THREADS = 64 * WAVES;
@@ -91,9 +93,11 @@ struct XRing {
 #ifdef NSOF_X_TIMING
 // Tuning build only (scripts/build_variant.sh xt farneback_iterate_x.hip -DNSOF_X_TIMING): constant-clock time that one wave
 // of each role of the workgroup with job (pair 0, strip 1) spends in each part of a step; read by scripts/x_timing.py.
-__device__ unsigned long long g_xt[32];
+__device__ unsigned long long g_xt[48];
 #define XT_DECL(on_)                                                        \
     const bool xt_on = (on_);                                               \
+    const bool xt_any = xt;                                                 \
+    unsigned long long xt_bar = 0;                                          \
     unsigned long long xt_acc[4] = {0, 0, 0, 0}, xt_prev = __builtin_amdgcn_s_memtime()
 #define XT_MARK(slot)                                                       \
     do {                                                                    \
@@ -101,16 +105,23 @@ __device__ unsigned long long g_xt[32];
         xt_acc[(slot) & 3] += xt_now - xt_prev;                             \
         xt_prev = xt_now;                                                   \
     } while (0)
+#define XT_BAR()                                                            \
+    do {                                                                    \
+        const unsigned long long xb0_ = __builtin_amdgcn_s_memtime();       \
+        __syncthreads();                                                    \
+        xt_bar += __builtin_amdgcn_s_memtime() - xb0_;                      \
+    } while (0)
 #define XT_FLUSH(base)                                                      \
     do {                                                                    \
         if (xt_on)                                                          \
             for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_xt[(base) + k_], xt_acc[k_]); \
+        if (xt_any && (threadIdx.x & 63) == 0) atomicAdd(&g_xt[32 + (threadIdx.x >> 6)], xt_bar); \
     } while (0)
 extern "C" int nsof_debug_xtiming(unsigned long long* out32, int reset)
 {
     if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_xt), sizeof(g_xt)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[32] = {};
+        unsigned long long z[48] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_xt), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -118,6 +129,7 @@ extern "C" int nsof_debug_xtiming(unsigned long long* out32, int reset)
 #else
 #define XT_DECL(on_)
 #define XT_MARK(slot)
+#define XT_BAR() __syncthreads()
 #define XT_FLUSH(base)
 #endif
 
@@ -160,12 +172,12 @@ __device__ __forceinline__ void x_rows_above(const XRing& ring, const Planes& R0
     }
 }
 
-// Barriers (all roles alike): Ba, Bb, then B(t) for t = 0 .. nimg-1.
-//   before Ba       step 0 (and the rows above the image)
-//   Ba .. Bb        step 1                  (consumers: column sums of step 0 -> D(0))
-//   Bb .. B(0)      step 2                  (consumers: column sums of step 1; scanner: step 0)
-//   B(t-1) .. B(t)  step t+2                (consumers: solve t-1, column sums of t+1; scanner: step t)
-// A ring of 2m+9 rows holds exactly the rows the consumers read in a step (2m+5) and the four being written.
+// Barriers (all roles alike): Ba, Bb, then B(t) for t = 0 .. nimg; "window t" = B(t-1) .. B(t), window -1 = Ba .. Bb.
+//   before Ba   producers: step 0 (and the rows above the image)
+//   window -1   producers: step 1;   consumers: column sums of step 0
+//   window t    producers: step t+2; consumers: solve, column sums of step t+1, publish D; scanner: segment 0 of step t
+//               and segment 1 of step t-1; I/O wave: carries (see x_remainder_loop)
+// A ring of 2m+9 rows holds exactly the rows the consumers read in a window (2m+5) and the four being written.
 // Full producer wave: thread <-> ring column, rows 2 GP, 2 GP + 1 of every step.
 template <int MH, int GP>
 __device__ __forceinline__ void x_producer_loop(const XRing& ring, const Planes& R0, const Planes& R1,
@@ -195,16 +207,16 @@ __device__ __forceinline__ void x_producer_loop(const XRing& ring, const Planes&
     step(std::integral_constant<int, 1>{}, 1);
     XT_DECL(xt && (threadIdx.x & 63) == 0);
     __syncthreads();                                                                 // Bb
-    for (int t = 0; t < nimg; t += 2) {
+    for (int t = 0; t <= nimg; t += 2) {
         XT_MARK(1);                                                                  // wait at the barrier
         step(std::integral_constant<int, 0>{}, t + 2);
         XT_MARK(0);                                                                  // rows
-        __syncthreads();                                                             // B(t)
-        if (t + 1 >= nimg) break;
+        XT_BAR();                                                                    // B(t)
+        if (t + 1 > nimg) break;
         XT_MARK(1);
         step(std::integral_constant<int, 1>{}, t + 3);
         XT_MARK(0);
-        __syncthreads();                                                             // B(t+1)
+        XT_BAR();                                                                    // B(t+1)
     }
     XT_FLUSH(8 + 8 * GP);
 }
@@ -272,24 +284,23 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
     fetch_finish(0);
     XT_DECL(xt && lane == 0);
     __syncthreads();                                                                 // Bb
-    for (int t = 0; t < nimg; t += 2) {
+    // window t: the scanner finishes segment 1 of step t-1 (its row-end sums: published in window t+1) and starts segment
+    // 0 of step t+1 in the next window (its row-start sums: fetched now)
+    auto window = [&](auto tsc, int t) {
+        constexpr int TS = decltype(tsc)::value;
         XT_MARK(1);
-        if (t >= 1) publish(t - 1);
+        if (t >= 2) publish(t - 2);
         if (t + 1 < nimg) fetch_issue(t + 1);
-        x_produce<MH>(in[0], fl[0], ring, R0, R1, F, W, H, xc, col, 4 * (t + 2) + MH + r);
+        x_produce<MH>(in[TS], fl[TS], ring, R0, R1, F, W, H, xc, col, 4 * (t + 2) + MH + r);
         XT_MARK(0);
         if (t + 1 < nimg) fetch_finish(t + 1);
         XT_MARK(2);
-        __syncthreads();                                                             // B(t)
-        if (t + 1 >= nimg) break;
-        XT_MARK(1);
-        publish(t);
-        if (t + 2 < nimg) fetch_issue(t + 2);
-        x_produce<MH>(in[1], fl[1], ring, R0, R1, F, W, H, xc, col, 4 * (t + 3) + MH + r);
-        XT_MARK(0);
-        if (t + 2 < nimg) fetch_finish(t + 2);
-        XT_MARK(2);
-        __syncthreads();                                                             // B(t+1)
+        XT_BAR();                                                                    // B(t)
+    };
+    for (int t = 0; t <= nimg; t += 2) {
+        window(std::integral_constant<int, 0>{}, t);
+        if (t + 1 > nimg) break;
+        window(std::integral_constant<int, 1>{}, t + 1);
     }
     publish(nimg - 1);
     XT_FLUSH(12);
@@ -332,10 +343,14 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
     int slot_new = (2 * MH + 1) % RL;           // stream index m    -> slot 2m+1
     int slot_old = 0;                           // stream index -m-1 -> slot 0
     const int x = x0 + j;
+    // The scanner works on the strip's two halves a step apart (segment 1 of step s in the window after segment 0 of step
+    // s), so the threads of the right half publish their D one window late (kept in registers meanwhile) and solve one
+    // window late: lag = 1.
+    const int lag = j >= G::SEG ? 1 : 0;
     XT_DECL(xt && j == 0);
-    // step s: four more rows enter the windows of this thread's two columns; D of the step goes to buffer s & 1
+    double Dreg[4][5];
+    // step s: four more rows enter the windows of this thread's two columns -> Dreg
     auto column_sums = [&](int s) {
-        double* svj = sv + (s & 1) * (G::SV1_BYTES / sizeof(double)) + j;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float na[5], oa[5], nb[5], ob[5];
@@ -349,7 +364,7 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
                 const float db = nb[c] - ob[c];
                 va[c] += (double)da;
                 vb[c] += (double)db;
-                svj[(q * 5 + c) * SVW] = va[c] - vb[c];
+                Dreg[q][c] = va[c] - vb[c];
             }
             if (vi_thread) {
 #pragma unroll
@@ -359,15 +374,27 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
             slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
         }
     };
+    // D of step p (held in Dreg) -> buffer p & 1, into slots this thread has read in this window (own column) or nobody
+    // reads any more
+    auto publish = [&](int p) {
+        if (p < 0 || p >= nimg) return;
+        double* svj = sv + (p & 1) * (G::SV1_BYTES / sizeof(double)) + j;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) svj[(q * 5 + c) * SVW] = Dreg[q][c];
+    };
     column_sums(0);
-    __syncthreads();   // Bb: D(0) is published, step 1 is in the ring
-    for (int t = 0; t <= nimg; t++) {
+    if (!lag) publish(0);
+    __syncthreads();   // Bb: D(0) of the left half is published, step 1 is in the ring
+    for (int t = 0; t <= nimg + 1; t++) {
         XT_MARK(1);        // wait at the barrier
-        if (t >= 1 && x < W) {   // solve step t-1: the scanner left g in buffer (t-1) & 1
-            const double* svj = sv + ((t - 1) & 1) * (G::SV1_BYTES / sizeof(double)) + j;
+        const int u = t - 1 - lag;   // the step whose g the scanner completed in the last window
+        if (u >= 0 && u < nimg && x < W) {
+            const double* svj = sv + (u & 1) * (G::SV1_BYTES / sizeof(double)) + j;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int yo = 4 * (t - 1) + q;
+                const int yo = 4 * u + q;
                 const double g11 = svj[(q * 5 + 0) * SVW] * scale, g12 = svj[(q * 5 + 1) * SVW] * scale;
                 const double g22 = svj[(q * 5 + 2) * SVW] * scale;
                 const double h1 = svj[(q * 5 + 3) * SVW] * scale, h2 = svj[(q * 5 + 4) * SVW] * scale;
@@ -377,16 +404,21 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
             }
         }
         XT_MARK(2);        // solve
-        if (t == nimg) break;
-        // D(t+1) takes the slots this thread has just read (same buffer, own column)
+        if (t == nimg + 1) break;
+        if (lag) publish(t);                       // right half: D(t), formed a window ago
         if (t + 1 < nimg) column_sums(t + 1);
+        if (!lag) publish(t + 1);                  // left half: D(t+1), at once
         XT_MARK(0);        // column sums
-        __syncthreads();   // B(t): scan of step t done, D(t+1) published, step t+2 in the ring
+        XT_BAR();          // B(t)
     }
     XT_FLUSH(0);
 }
 
-// ---- the scanner wave: lane l = q * 5 + c <-> (row q, plane c) of the step -------------------------------------------
+// ---- the scanner wave -------------------------------------------------------------------------------------------------
+// Bound by instruction issue (~28 clocks per column whatever the number of active lanes), so the strip is scanned as two
+// segments of 96 columns by two groups of 20 lanes running the SAME instruction stream a step apart: in window t lanes 0-19
+// (lane = q * 5 + c <-> row q, plane c) scan columns 0..95 of step t, lanes 20-39 columns 96..191 of step t-1, starting from
+// the value the first group ended on a window earlier.
 template <int MH>
 __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, double* cb, bool has_left, int nimg, int ncols,
                                                int lane, bool xt)
@@ -394,21 +426,26 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
     using G = XGeom<MH>;
     constexpr int SVW = G::SVW;
     typedef double d2 __attribute__((ext_vector_type(2)));
-    const bool act = lane < 20;
-    const int l = act ? lane : 0;
+    const int seg = lane >= 20 ? 1 : 0;
+    const int l = lane < 40 ? lane - 20 * seg : 0;
+    double Smid = 0.;   // lanes 0-19: where segment 0 of the previous step ended
     __syncthreads();   // Ba
     __builtin_amdgcn_s_setprio(3);   // the one dependent chain every other wave of the step ends up waiting for
     __syncthreads();   // Bb
     XT_DECL(xt && lane == 0);
-    for (int t = 1; t <= nimg; t++) {   // iteration t scans step t-1
+    for (int t = 0; t <= nimg; t++) {   // window t
         XT_MARK(6);    // wait at the barrier
-        d2* row = reinterpret_cast<d2*>(sv + ((t - 1) & 1) * (G::SV1_BYTES / sizeof(double)) + l * SVW);
-        if (act) {
+        const int step = t - seg;
+        const double Sleft = __shfl(Smid, lane >= 20 ? lane - 20 : lane);
+        d2* row = reinterpret_cast<d2*>(sv + (step & 1) * (G::SV1_BYTES / sizeof(double)) + l * SVW + seg * G::SEG);
+        if (lane < 40 && step >= 0 && step < nimg) {
             double S;
-            if (has_left) {
-                S = cb[40 + ((t - 1) & 1) * 20 + l];   // fetched by the I/O wave a step ago
+            if (seg) {
+                S = Sleft;
+            } else if (has_left) {
+                S = cb[40 + (step & 1) * 20 + l];   // fetched by the I/O wave a window ago
             } else {
-                const double* vi = vinit + (((t - 1) & 1) * 20 + l) * MH;
+                const double* vi = vinit + ((step & 1) * 20 + l) * MH;
                 S = vi[0] * (double)(MH + 2);
 #pragma unroll
                 for (int k = 1; k < MH; k++) S += vi[k];
@@ -528,10 +565,11 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
                     : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
 
             }
-            cb[((t - 1) & 1) * 20 + l] = S;   // the row-end sums: the I/O wave hands them to the right neighbour
+            if (seg) cb[(step & 1) * 20 + l] = S;   // the row-end sums: the I/O wave hands them to the right neighbour
+            else Smid = S;
         }
         XT_MARK(5);        // scan
-        __syncthreads();   // B(t-1): g of step t-1 is complete
+        XT_BAR();          // B(t)
     }
     XT_FLUSH(4);
 }
@@ -612,7 +650,7 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
         float2* Fout = reinterpret_cast<float2*>(flow_out) + (HET ? 0 : (size_t)pair * plane);
         x_consumer_loop<MH>(ring, sv, vinit, Fout, fpitch, W, H, x0, tid, nimg, 1. / (block_size * block_size), strip == 0, xt);
     } else if (wave == G::NCW) {
-        const int ncols = min(SW, (W - x0 + 7) & ~7);
+        const int ncols = min(G::SEG, (W - x0 + 7) & ~7);   // columns of a segment's instruction stream
         x_scanner_loop<MH>(sv, vinit, cb, strip > 0, nimg, ncols, tid & 63, xt);
     } else {
         // producers: waves NCW+1 .. NCW+NB rows 0,1 of blocks 0..NB-1; wave NCW+NB+1 the remainder; then rows 2,3

@@ -217,7 +217,10 @@ extern "C" int nsof_create(int device, nsof_ctx** out)
     ctx->stream = ctx->own_stream;
     if (const char* e = getenv("NSOF_POLYEXP_F32")) ctx->opt_polyexp_f32 = (e[0] && e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("NSOF_EXACT_ROWSUMS")) ctx->opt_exact_rowsums = (e[0] && e[0] != '0') ? 1 : 0;
-    if (const char* e = getenv("NSOF_ROW_BANDS")) ctx->opt_row_bands = std::max(0, atoi(e));
+    if (const char* e = getenv("NSOF_ROW_BANDS")) {
+        const int v = atoi(e);
+        ctx->opt_row_bands = v < 0 || v == 2 || v == 3 ? 0 : v;
+    }
     *out = ctx;
     return NSOF_OK;
 }
@@ -261,16 +264,14 @@ extern "C" int nsof_set_stream(nsof_ctx* ctx, void* s)
 extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
 {
     if (!ctx) return NSOF_EINVAL;
-    if (option == NSOF_OPT_POLYEXP_F32) {
-        ctx->opt_polyexp_f32 = value ? 1 : 0;
-        return NSOF_OK;
-    }
-    if (option == NSOF_OPT_EXACT_ROWSUMS) {
-        ctx->opt_exact_rowsums = value ? 1 : 0;
+    if (option == NSOF_OPT_POLYEXP_F32 || option == NSOF_OPT_EXACT_ROWSUMS) {
+        if (value != 0 && value != 1) return nsof_set_error(ctx, NSOF_EINVAL, "option %d takes 0 or 1", option);
+        (option == NSOF_OPT_POLYEXP_F32 ? ctx->opt_polyexp_f32 : ctx->opt_exact_rowsums) = value;
         return NSOF_OK;
     }
     if (option == NSOF_OPT_ROW_BANDS) {
-        if (value < 0) return nsof_set_error(ctx, NSOF_EINVAL, "NSOF_OPT_ROW_BANDS: 0 (off), 1 (automatic) or a row count");
+        if (value < 0 || value == 2 || value == 3)
+            return nsof_set_error(ctx, NSOF_EINVAL, "NSOF_OPT_ROW_BANDS: 0 (off), 1 (automatic) or a row count >= 4");
         ctx->opt_row_bands = value;
         return NSOF_OK;
     }

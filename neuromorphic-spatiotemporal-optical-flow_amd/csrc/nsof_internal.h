@@ -25,7 +25,7 @@ struct nsof_ctx {
     unsigned prof_mask = 0;
     nsof_prof_slot prof[NSOF_K_COUNT];
     int opt_polyexp_f32 = 0;   // NSOF_OPT_POLYEXP_F32
-    int opt_exact_rowsums = 0; // NSOF_OPT_EXACT_ROWSUMS
+    int opt_exact_rowsums = 1; // NSOF_OPT_EXACT_ROWSUMS (default: the library's row-sum order)
     int opt_row_bands = 0;     // NSOF_OPT_ROW_BANDS: 0 off, 1 automatic, >= 4 rows per band
     char err[512] = {0};
     // reusable device workspace of the Farneback driver

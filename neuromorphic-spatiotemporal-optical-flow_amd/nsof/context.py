@@ -21,7 +21,9 @@ def dev_ptr(obj):
 
 
 class Context:
-    """Owns an ``nsof_ctx``.  Not thread-safe; create one per thread / per GPU."""
+    """Owns an ``nsof_ctx``.  One per thread / per GPU is the intended use; ``lock`` (re-entrant) serialises the entry points
+    that change options around a call (``calcOpticalFlowFarneback(exact=..., low_latency=...)``) for callers that share
+    one context, e.g. the process-wide ``default_context()``."""
 
     def __init__(self, device=None):
         self._lib = _lib.load()
@@ -32,6 +34,7 @@ class Context:
         rc = self._lib.nsof_create(self.device, C.byref(p))
         raise_for_status(rc, None, "nsof_create")
         self._p = p
+        self.lock = threading.RLock()
 
     # -- plumbing -------------------------------------------------------------------------
     @property

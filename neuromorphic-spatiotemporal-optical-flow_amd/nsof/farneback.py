@@ -59,12 +59,15 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     """Same signature and result as ``cv2.calcOpticalFlowFarneback``: float32 (H, W, 2), (u, v) interleaved,
     such that ``next(x+u, y+v) ~ prev(x, y)``.  ``flow=None`` allocates; a matching float32 array is reused.
     ``exact`` (keyword only): True = box-filter row sums in the library's own order for this call
-    (``NSOF_OPT_EXACT_ROWSUMS``: bit-identical to the CPU restatement on any input, about half the throughput),
-    False = the default per-pixel sums, None = whatever the context / ``install(exact=...)`` says.
-    ``low_latency`` (keyword only): True = row bands in the iteration kernel for this call (``NSOF_OPT_ROW_BANDS``:
-    a lone 1080p call drops from 3.7 to 1.1 ms; column sums restart per band, so the flow moves in its 5th decimal,
-    more where the 2x2 system is rank deficient -- the automatic mode therefore applies from winsize 9 up); ignored
-    together with ``exact=True``."""
+    (``NSOF_OPT_EXACT_ROWSUMS``, the context's default: bit-identical to the CPU restatement on any input),
+    False = the fast mode (each pixel's window summed directly: a few per cent faster, up to ~8e-4 off where 2x2 systems
+    are rank deficient), None = whatever the context / ``install(exact=...)`` says.
+    ``low_latency`` (keyword only): True = the fast mode with row bands in the iteration kernel for this call
+    (``NSOF_OPT_ROW_BANDS``: a lone 1080p call drops from 3.7 to 1.1 ms; column sums restart per band, so the flow moves
+    in its 5th decimal, more where the 2x2 system is rank deficient -- the automatic mode therefore applies from winsize
+    9 up); ignored together with an explicit ``exact=True``.
+    The two keywords set context options around the call; the context's lock makes that safe for concurrent callers of
+    one context."""
     prev = _as_gray_u8(prev, "prev")
     next = _as_gray_u8(next, "next")  # noqa: A001
     if prev.shape != next.shape:
@@ -80,23 +83,26 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     ctx = ctx or default_context()
     exact = _DEFAULT_EXACT if exact is None else exact
     low_latency = _DEFAULT_LOW_LATENCY if low_latency is None else low_latency
-    saved = saved_bands = None
-    if exact is not None:
-        saved = ctx.get_option(_lib.OPT_EXACT_ROWSUMS)
-        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1 if exact else 0)
-    if low_latency is not None:
-        saved_bands = ctx.get_option(_lib.OPT_ROW_BANDS)
-        ctx.set_option(_lib.OPT_ROW_BANDS, 1 if low_latency else 0)
-    try:
-        rc = ctx._lib.nsof_farneback_u8(ctx.ptr, prev.ctypes.data, prev.strides[0], next.ctypes.data, next.strides[0],
-                                        w, h, out.ctypes.data, out.strides[0], float(pyr_scale), int(levels),
-                                        int(winsize), int(iterations), int(poly_n), float(poly_sigma), int(flags))
-    finally:
-        if saved is not None:
-            ctx.set_option(_lib.OPT_EXACT_ROWSUMS, saved)
-        if saved_bands is not None:
-            ctx.set_option(_lib.OPT_ROW_BANDS, saved_bands)
-    ctx.check(rc, "calcOpticalFlowFarneback")
+    if low_latency and exact is None:
+        exact = False   # row bands belong to the fast row-sum mode
+    with ctx.lock:
+        saved = saved_bands = None
+        if exact is not None:
+            saved = ctx.get_option(_lib.OPT_EXACT_ROWSUMS)
+            ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1 if exact else 0)
+        if low_latency is not None:
+            saved_bands = ctx.get_option(_lib.OPT_ROW_BANDS)
+            ctx.set_option(_lib.OPT_ROW_BANDS, 1 if low_latency else 0)
+        try:
+            rc = ctx._lib.nsof_farneback_u8(ctx.ptr, prev.ctypes.data, prev.strides[0], next.ctypes.data, next.strides[0],
+                                            w, h, out.ctypes.data, out.strides[0], float(pyr_scale), int(levels),
+                                            int(winsize), int(iterations), int(poly_n), float(poly_sigma), int(flags))
+        finally:
+            if saved is not None:
+                ctx.set_option(_lib.OPT_EXACT_ROWSUMS, saved)
+            if saved_bands is not None:
+                ctx.set_option(_lib.OPT_ROW_BANDS, saved_bands)
+        ctx.check(rc, "calcOpticalFlowFarneback")
     return out
 
 
@@ -306,9 +312,10 @@ _saved_cv2_fn = None
 
 def install(cv2_module=None, exact=None, low_latency=None):
     """Assign ``calcOpticalFlowFarneback`` onto ``cv2`` (the reference looks the attribute up at call
-    time, so its scripts then run on the GPU unmodified).  Returns the patched module.  ``exact=True`` makes every
-    call through the drop-in use the library's own row-sum order (bit-faithful on any footage, see DESIGN.md section 2);
-    ``low_latency=True`` makes every call use row bands (one call per camera frame: 1.4 instead of 4.1 ms at 1080p)."""
+    time, so its scripts then run on the GPU unmodified).  Returns the patched module.  ``exact=False`` makes every
+    call through the drop-in use the fast row-sum mode instead of the library's own order (the default, bit-faithful on
+    any footage); ``low_latency=True`` makes every call use that mode with row bands (one call
+    per camera frame: 1.1 instead of 3.7 ms at 1080p)."""
     global _saved_cv2_fn, _DEFAULT_EXACT, _DEFAULT_LOW_LATENCY
     _DEFAULT_EXACT = exact
     _DEFAULT_LOW_LATENCY = low_latency

@@ -2,10 +2,12 @@
 """Parity soak: many seeded (shape, parameter) cases of the whole Farneback call, HIP path vs CPU oracle.
 Not part of the test-suite (minutes of CPU oracle time); prints one JSON summary line.
 
-    python scripts/soak_parity.py [--cases 400] [--seed 7] [--mode default|exact|fast]
+    python scripts/soak_parity.py [--cases 400] [--seed 7] [--mode default|fastrows|fast]
 
---mode exact  NSOF_OPT_EXACT_ROWSUMS (row sums in the library's order: expected bit-identical everywhere)
---mode fast   NSOF_OPT_POLYEXP_F32 (float polynomial expansion: NOT bit-identical; the summary gives the error)
+--mode default   the library's operation order in every stage (NSOF_OPT_EXACT_ROWSUMS=1): expected bit-identical everywhere
+                 (NSOF_EXACT_IMPL=2k in the environment runs the older two-kernel form of the same order)
+--mode fastrows  NSOF_OPT_EXACT_ROWSUMS=0 (per-pixel window sums: deviates at rank-deficient windows)
+--mode fast      NSOF_OPT_POLYEXP_F32 (float polynomial expansion: NOT bit-identical; the summary gives the error)
 A quarter of the cases are "low texture" frames (flat blocks, straight bars, a little noise: rank-deficient windows
 as real footage has them), where the last bits of the sums decide the flow's 4th decimal."""
 import argparse
@@ -22,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--mode", choices=["default", "exact", "fast"], default="default")
+    ap.add_argument("--mode", choices=["default", "exact", "fastrows", "fast"], default="default")
     a = ap.parse_args()
     os.environ.setdefault("NSOF_SKIP_BUILD", "1")
     import numpy as np
@@ -32,8 +34,10 @@ def main():
     rng = np.random.default_rng(a.seed)
     ctx = nsof.Context(0)
     from nsof import _lib
-    if a.mode == "exact":
+    if a.mode in ("default", "exact"):
         ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
+    elif a.mode == "fastrows":
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
     elif a.mode == "fast":
         ctx.set_option(_lib.OPT_POLYEXP_F32, 1)
     above = {"1e-5": 0, "1e-4": 0, "1e-3": 0}

@@ -44,7 +44,7 @@ raw.nsof_debug_xtiming(None, 1)
 ctx.prof_enable(_lib.K_ITERATE)
 ctx.check(lib.nsof_stage_iterate(ctx.ptr, n, R.data_ptr(), flow_a.data_ptr(), w, h, a.winsize, flow_b.data_ptr()))
 ms, cnt = ctx.prof_collect(_lib.K_ITERATE)
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 48)()
 raw.nsof_debug_xtiming(out, 0)
 steps = (h + 3) // 4 + 1
 names = ["consumer: column sums", "consumer: wait at barrier", "consumer: solve", "-",
@@ -58,4 +58,6 @@ for k, nm in enumerate(names):
 for role, sl in (("consumer", range(0, 4)), ("scanner", range(4, 8)), ("producer 0,1", range(8, 12)), ("remainder", range(12, 16)),
                  ("producer 2,3", range(16, 20))):
     print(f"  {role} total {sum(out[k] for k in sl) / steps:9.1f}")
+print("  barrier wait per wave (0-2 consumers, 3 scanner, 4-6 rows 0,1, 7 remainder, 8-10 rows 2,3):")
+print("   ", " ".join(f"{out[32 + k] / steps:7.0f}" for k in range(11)))
 ctx.close()

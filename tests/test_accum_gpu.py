@@ -478,3 +478,34 @@ def test_block_current_on_device_equals_host_reduction(nsof_lib, ctx):
     for ms, got in cur.items():
         assert np.array_equal(got, pipeline.surface_to_block_current(r_now, ms))
     assert dev[20][-1].max() > dev[20][-1].min()
+
+
+def test_config5_pipeline_flow_vs_oracle_chain(nsof_lib, ctx, oracle):
+    """BASELINE config 5 joined (events -> leaky-integrate surface -> 8-bit frames -> Farneback between consecutive
+    surface frames, nsof.pipeline.events_to_flow_sequence) at a reduced sensor against the oracle CHAIN:
+    oracle/accum_ref.c for the slices -> uint8(255 w) -> oracle/farneback_ref.c.  The surface frames -- a flat field plus
+    sparse dots -- are the low-texture class where rank-deficient 2x2 systems amplify the last bits of the box sums, so
+    this is the leg that needs the library's row-sum order: frames byte-identical, flows bit-identical in the default
+    mode; the opt-in fast row sums stay finite and close but are not held to 1e-4 here."""
+    import torch
+    from nsof import _lib, pipeline, synth
+    from nsof.farneback import PARAMS_A
+    W, H, every = 640, 360, 33   # noqa: N806
+    x, y, p, t = synth.make_events(31, W, H, 60_000, 140_000, box=(60, 40))
+    frames, flows = pipeline.events_to_flow_sequence(x, y, p, t, (H, W), snapshot_every=every, ctx=ctx)
+    n_frames = frames.shape[0]
+    assert n_frames >= 3
+    gf, gfl = frames.cpu().numpy(), flows.cpu().numpy()
+    pa = [getattr(PARAMS_A, k) for k in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    ref_frames = []
+    for k in range(3):
+        _, w = oracle.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=(k + 1) * every, n_threads=4)
+        ref_frames.append((np.float32(255.0) * w).astype(np.uint8))
+        assert np.array_equal(gf[k], ref_frames[k]), k
+    assert int(gf[2].max()) > int(gf[2].min())                     # events did move the surface
+    for k in range(2):
+        ref = oracle.farneback(ref_frames[k], ref_frames[k + 1], *pa)
+        assert np.array_equal(gfl[k], ref), (k, float(np.abs(gfl[k] - ref).max()))
+    fast = nsof_lib.calcOpticalFlowFarneback(gf[0], gf[1], None, *pa, ctx=ctx, exact=False)
+    assert np.isfinite(fast).all()
+    assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1

@@ -43,6 +43,19 @@ def test_bench_json_contract():
     assert a["roofline_fused_bytes"]["frac"] > 0 and a["roofline_survey_definition"]["bytes_per_slice"] > 6e7
     assert d["config5"]["flow_finite"] is True and d["config5"]["surface_frames"] >= 2
     assert d["parity_ok"] is True
+    # round 3: the library's row-sum order is the default -> the headline batch, the reference's real frames and the first
+    # pair of the joined config-5 pipeline are all bit-identical to the oracle; the per-pixel sums are a named fast mode
+    assert "library order" in d["config"]["rowsum_order"] and d["bit_identical_to_oracle"] is True
+    c5 = d["config5"]
+    assert c5["parity_ok"] is True and c5["first_pair_vs_oracle_chain"]["surface_frames_equal"] is True
+    assert c5["first_pair_vs_oracle_chain"]["default"]["max_abs_epe_vs_oracle"] < 1e-4
+    rf = d["real_frames"]
+    assert rf["parity_ok"] is True
+    for name in ("autodriving_801x801_params_B", "grasp_1080x1920_params_A"):
+        assert rf[name]["default"]["bit_identical"] is True and rf[name]["default"]["pixels_above_1e-4"] == 0
+    assert rf["autodriving_801x801_params_B"]["fast_rowsums"]["max_abs_epe_vs_oracle"] > 1e-4   # why it is opt-in
+    fr = d["fast_rowsums"]
+    assert fr["value"] > 0 and fr["max_abs_vs_default_path"] < 1e-4
     # the other two parameter sets of the reference's datasets, consecutive-frame mode, lone-call latency
     for key in ("params_B", "params_C"):
         q = d[key]
@@ -51,6 +64,7 @@ def test_bench_json_contract():
     assert d["sequence"]["value"] > 0 and d["sequence"]["last_pair_identical_to_pair_call"] is True
     sc = d["single_call"]
     assert sc["default"]["host_to_host_ms"] > 0 and sc["row_bands"]["device_resident_ms"] > 0
+    assert sc["fast_rowsums"]["host_to_host_ms"] > 0
     assert sc["row_bands"]["max_abs_vs_default"] < 1e-3
 
 

@@ -430,7 +430,8 @@ def test_polyexp_float_mode_is_opt_in_and_close(ctx, nsof_lib, torch_dev):
 
 @pytest.mark.gpu
 def test_row_bands_mode_is_opt_in_and_close(ctx, nsof_lib, oracle):
-    """NSOF_OPT_ROW_BANDS (low-latency mode for lone calls): off by default; on, every strip of the iteration kernel is
+    """NSOF_OPT_ROW_BANDS (low-latency mode for lone calls of the FAST row-sum mode, NSOF_OPT_EXACT_ROWSUMS = 0): off by
+    default; on, every strip of that mode's iteration kernel is
     cut into row bands whose column sums start from a direct sum instead of the library's running sum from row 0 --
     same numbers to ~1e-16, hence a flow that stays inside the oracle tolerance on textured frames (params A, wide
     window) and moves in the 4th decimal where 3x3 windows are rank deficient (params B; same sensitivity as the
@@ -439,7 +440,19 @@ def test_row_bands_mode_is_opt_in_and_close(ctx, nsof_lib, oracle):
     than one band (no split: bit-identical to the default) are covered."""
     from nsof import _lib, synth
     assert ctx.get_option(_lib.OPT_ROW_BANDS) == 0
-    assert ctx._lib.nsof_set_option(ctx.ptr, _lib.OPT_ROW_BANDS, -1) == _lib.NSOF_EINVAL
+    assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1          # the library's row-sum order is the default
+    for bad in (-1, 2, 3):
+        assert ctx._lib.nsof_set_option(ctx.ptr, _lib.OPT_ROW_BANDS, bad) == _lib.NSOF_EINVAL
+    assert ctx._lib.nsof_set_option(ctx.ptr, _lib.OPT_EXACT_ROWSUMS, 2) == _lib.NSOF_EINVAL
+    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)                   # row bands belong to the fast row-sum mode
+    try:
+        _row_bands_body(ctx, nsof_lib, oracle)
+    finally:
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
+
+
+def _row_bands_body(ctx, nsof_lib, oracle):
+    from nsof import _lib, synth
     ns = 1e-4   # the north-star tolerance (max-abs end-point error)
     cases = [((1080, 1920), A, 1, ns), ((203, 317), A, 32, ns), ((203, 317), A, 4, ns),
              ((135, 240), Cc, 8, 1e-3), ((801, 801), B, 32, 1e-3), ((801, 801), B, 1, 0.0), ((30, 200), A, 32, 0.0)]
@@ -510,6 +523,7 @@ def test_batches_larger_than_memory_are_chunked(nsof_lib, ctx, torch_dev, monkey
     frames = np.stack([np.ascontiguousarray(base[5 + 2 * i:5 + 2 * i + h, 3 * i:3 * i + w]) for i in range(n + 1)])
     d = _dev(torch_dev, frames)
     P = nsof_lib.FarnebackParams(*A)
+    saved = ctx.get_option(_lib.OPT_EXACT_ROWSUMS)
     for exact in (0, 1):
         ctx.set_option(_lib.OPT_EXACT_ROWSUMS, exact)
         try:
@@ -529,7 +543,7 @@ def test_batches_larger_than_memory_are_chunked(nsof_lib, ctx, torch_dev, monkey
                 assert np.array_equal(res[cap][0], res[None][0]) and np.array_equal(res[cap][1], res[None][1]), (exact, cap)
             assert np.array_equal(res[None][0], res[None][1])
         finally:
-            ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
+            ctx.set_option(_lib.OPT_EXACT_ROWSUMS, saved)
 
 
 @pytest.mark.gpu

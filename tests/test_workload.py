@@ -272,22 +272,16 @@ def test_real_frames_through_harness(nsof_lib, ctx, oracle, stacks):
         assert fr[0].shape == wl.DATASET_FRAMES[name][:2]
     calls, _ = wl.mixed_workload(stacks, frames=frames, pairs_per_dataset=2)
     wl.run_calls(calls, ctx=ctx)
-    # Tolerance on REAL frames.  Every stage but one keeps the reference's operation order (bit-exact); the box-filter
-    # ROW sums are formed per pixel in double instead of as the library's running sum along the whole row.  On the
-    # textured synthetic frames that never shows (0.0).  Real frames contain windows where the 2x2 system is rank
-    # deficient (straight edges, flat areas: g11*g22 - g12^2 cancels to the 1e-3 regulariser) and there the last
-    # bits of the double sums decide the 4th decimal of the flow: with the 3x3 window of parameter set B, 80 of
-    # 641 601 pixels of the first autodriving pair move by more than 1e-4 (max 7.8e-4) -- reproduced on the CPU by
-    # changing nothing but that summation order in the oracle.  See DESIGN.md section 2.
+    # REAL frames, default mode: every stage keeps the reference's operation order, the box-filter row sums included (one
+    # running sum per image row, carried from strip to strip inside the fused iteration kernel) -> bit-identical to the
+    # oracle.  (Round 2's default summed each pixel's window directly: 80 of 641 601 pixels of the first autodriving pair
+    # then moved by more than 1e-4, max 7.8e-4, because rank-deficient 3x3 windows amplify the sums' last bits; that is
+    # now the opt-in fast mode, see test_fast_rowsum_mode_deviates_where_documented.)
     for c in calls:
         ref = oracle.farneback(np.ascontiguousarray(c.prev), np.ascontiguousarray(c.next),
                                *[getattr(c.params, k) for k in ("pyr_scale", "levels", "winsize", "iterations",
                                                                 "poly_n", "poly_sigma", "flags")])
-        d = np.abs(c.flow - ref).max(-1)
-        assert float(d.max()) <= 2e-3, (c.dataset, c.kind, c.rect, float(d.max()))
-        assert (d > 1e-4).mean() <= 5e-4, (c.dataset, c.kind, c.rect, float((d > 1e-4).mean()))
-        if c.params.winsize >= 15:           # parameter set A: well conditioned windows
-            assert float(d.max()) <= 1e-5, (c.dataset, c.kind, c.rect, float(d.max()))
+        assert np.array_equal(c.flow, ref), (c.dataset, c.kind, c.rect, float(np.abs(c.flow - ref).max()))
 
 
 @pytest.mark.gpu
@@ -319,10 +313,11 @@ def test_roi_batch_is_cheaper_than_one_by_one(nsof_lib, ctx, torch_dev):
 
 @pytest.mark.gpu
 def test_exact_rowsum_order_equals_oracle_on_real_frames(nsof_lib, ctx, oracle, stacks):
-    """NSOF_OPT_EXACT_ROWSUMS: with the box-filter row sums formed in the library's order (one running sum per image
-    row) the HIP path equals the CPU oracle BIT FOR BIT on the reference's real frames too -- the 801x801 autodriving
-    pair with the 3x3 window of parameter set B, where the default path differs by up to 7.8e-4 at 80 pixels -- through
-    the per-call entry, the uniform batch and the work list."""
+    """Default mode (NSOF_OPT_EXACT_ROWSUMS = 1): with the box-filter row sums formed in the library's order (one running
+    sum per image row) the HIP path equals the CPU oracle BIT FOR BIT on the reference's real frames -- the 801x801
+    autodriving pairs with the 3x3 window of parameter set B, where per-pixel window sums differ by up to 7.8e-4 at 80
+    pixels -- through the per-call entry, the uniform batch / sequence and the work list; the older two-kernel form of the
+    same order (NSOF_EXACT_IMPL=2k is read once per process, so it is not exercised here) is covered by the soak script."""
     pil = pytest.importorskip("PIL.Image")
     import torch
     from nsof import _lib, gating
@@ -333,35 +328,47 @@ def test_exact_rowsum_order_equals_oracle_on_real_frames(nsof_lib, ctx, oracle, 
     B = (0.6, 3, 3, 3, 10, 1.05, 0)
     p = nsof.FarnebackParams(*B)
     refs = [oracle.farneback(fr[i], fr[i + 1], *B) for i in range(2)]
-    if not ctx.get_option(_lib.OPT_EXACT_ROWSUMS):                      # (NSOF_EXACT_ROWSUMS=1 makes it the default)
-        default = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
-        assert 1e-4 < float(np.abs(default - refs[0]).max()) < 2e-3      # the documented deviation of the default path
-    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
-    try:
-        assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1
-        one = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
-        lst = nsof.farneback_pairs([(fr[0], fr[1]), (fr[1], fr[2]), (fr[0][100:400, 50:700], fr[1][100:400, 50:700])], p, ctx=ctx)
-        dev = torch.device("cuda", 0)
-        frames = torch.from_numpy(np.stack(fr)).to(dev)
-        flows = torch.empty((2, 801, 801, 2), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize()
-        nsof.farneback_sequence(frames, flows, 3, 801, 801, p, ctx=ctx)
-        ctx.synchronize()
-    finally:
-        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
+    assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1
+    one = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx)
+    lst = nsof.farneback_pairs([(fr[0], fr[1]), (fr[1], fr[2]), (fr[0][100:400, 50:700], fr[1][100:400, 50:700])], p, ctx=ctx)
+    dev = torch.device("cuda", 0)
+    frames = torch.from_numpy(np.stack(fr)).to(dev)
+    flows = torch.empty((2, 801, 801, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    nsof.farneback_sequence(frames, flows, 3, 801, 801, p, ctx=ctx)
+    ctx.synchronize()
     assert np.array_equal(one, refs[0])
-    assert np.array_equal(nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx, exact=True), refs[0])   # per call
-    assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 0                                                          # ... and restored
     assert np.array_equal(lst[0], refs[0]) and np.array_equal(lst[1], refs[1])
     assert np.array_equal(lst[2], oracle.farneback(np.ascontiguousarray(fr[0][100:400, 50:700]),
                                                    np.ascontiguousarray(fr[1][100:400, 50:700]), *B))
     assert np.array_equal(flows.cpu().numpy(), np.stack(refs))
-    # parameter set A on the synthetic pair: exact too (and the default path already is)
+    # parameter set A on a synthetic pair
     from nsof import synth
     a, b = synth.make_pair(3, 270, 480)
-    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
+    assert np.array_equal(nsof.calcOpticalFlowFarneback(a, b, None, *A, ctx=ctx), oracle.farneback(a, b, *A))
+
+
+@pytest.mark.gpu
+def test_fast_rowsum_mode_deviates_where_documented(nsof_lib, ctx, oracle):
+    """NSOF_OPT_EXACT_ROWSUMS = 0 (opt-in fast mode: each pixel's window summed directly): within 1e-5 of the oracle on
+    textured frames, and above 1e-4 (below 2e-3) on the real autodriving pair with parameter set B -- the deviation
+    DESIGN.md section 2 documents; per call through the exact= keyword, which restores the context's setting."""
+    pil = pytest.importorskip("PIL.Image")
+    from nsof import _lib, gating, synth
+    nsof = nsof_lib
+    d = os.path.join(GOLDEN, "frames", "autodriving")
+    fr = [gating.frame_to_gray(np.ascontiguousarray(np.asarray(pil.open(os.path.join(d, f"{k}.jpg")).convert("RGB"))[..., ::-1]),
+                               "RGB2GRAY") for k in (1, 2)]
+    B = (0.6, 3, 3, 3, 10, 1.05, 0)
+    ref = oracle.farneback(fr[0], fr[1], *B)
+    fast = nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx, exact=False)
+    assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1                      # restored
+    assert 1e-4 < float(np.abs(fast - ref).max()) < 2e-3
+    ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
     try:
-        ex = nsof.calcOpticalFlowFarneback(a, b, None, *A, ctx=ctx)
+        a, b = synth.make_pair(3, 270, 480)
+        assert float(np.abs(nsof.calcOpticalFlowFarneback(a, b, None, *A, ctx=ctx) - oracle.farneback(a, b, *A)).max()) <= 1e-5
+        assert np.array_equal(nsof.calcOpticalFlowFarneback(fr[0], fr[1], None, *B, ctx=ctx, exact=True), ref)
+        assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 0
     finally:
-        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 0)
-    assert np.array_equal(ex, oracle.farneback(a, b, *A))
+        ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
