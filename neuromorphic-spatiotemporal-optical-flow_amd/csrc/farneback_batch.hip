@@ -245,7 +245,7 @@ std::vector<int> node_cpus(int node)
     return out;
 }
 
-int g_pack_node = -1;   // NUMA node the packing threads prefer (set per call from the context's device)
+thread_local int g_pack_node = -1;   // NUMA node the packing threads of THIS calling thread prefer (set per call from the context's device)
 
 void parallel_rows(size_t n_tasks, const std::function<void(size_t)>& fn)
 {
@@ -448,6 +448,8 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
 
     const int nc = (int)chunks.size();
     constexpr int NS = nsof_pipe::NSLOT;
+    const char* fail_env = getenv("NSOF_PIPE_FAIL_AFTER_CHUNK");
+    const int fail_after = fail_env ? atoi(fail_env) : -1;
     // NSOF_PIPE_TRACE=1: device-side begin/end of every stage of every chunk (timing events), printed at the end
     const bool trace = getenv("NSOF_PIPE_TRACE") != nullptr;
     std::vector<std::array<hipEvent_t, 6>> tev(trace ? nc : 0);
@@ -461,6 +463,23 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
     };
     std::vector<nsof_pair_desc> dd;
     std::vector<char> finished(nc, 0);
+    // Any early return below leaves copies in flight: uploads out of the caller's / the slots' pinned memory, downloads INTO
+    // the caller's flow arrays.  The caller is free to release those buffers as soon as it sees the error, so every
+    // non-OK exit drains the three streams first (and drops the trace events); the next call then finds idle slots.
+    struct Drain {
+        nsof_ctx* ctx; nsof_pipe* pp; std::vector<std::array<hipEvent_t, 6>>* tev; bool ok = false;
+        ~Drain()
+        {
+            if (ok) return;
+            (void)hipStreamSynchronize(pp->s_in);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(pp->s_out);
+            for (auto& a : *tev)
+                for (auto e : a)
+                    if (e) (void)hipEventDestroy(e);
+        }
+    } drain{ctx, pp, &tev};
+    for (auto& a : tev) a.fill(nullptr);
     for (int ci = 0; ci < nc; ci++) {
         const Chunk& c = chunks[ci];
         nsof_pipe::Slot& s = pp->slot[ci % NS];
@@ -541,6 +560,8 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
         }
         mark(ci, 2, ctx->stream);
         if ((rc = het_core(ctx, c.hi - c.lo, dd.data(), p))) return rc;
+        if (fail_after >= 0 && ci == fail_after)   // NSOF_PIPE_FAIL_AFTER_CHUNK (tests): an error with copies in flight
+            return nsof_set_error(ctx, NSOF_ENOMEM, "NSOF_PIPE_FAIL_AFTER_CHUNK=%d: injected failure", fail_after);
         NSOF_HIP(ctx, hipEventRecord(s.compute_done, ctx->stream));
         mark(ci, 3, ctx->stream);
         // stage 3: flow -> host
@@ -583,6 +604,7 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
         for (auto& a : tev)
             for (auto e : a) hipEventDestroy(e);
     }
+    drain.ok = true;
     return NSOF_OK;
 }
 

@@ -58,8 +58,11 @@ struct XGeom {
     static_assert(SW + HALO <= COLS && SW % 8 == 0, "strip geometry");
     static constexpr int NB = COLS / 64, REM = COLS % 64;   // full 64-column producer blocks, columns of the remainder wave
     static_assert(REM == 16, "the remainder wave maps 4 rows x 16 columns onto its 64 lanes");
-    static constexpr int SEG = SW / 2;                      // the strip's two scan segments (see x_scanner_loop)
-    static_assert(SEG % 8 == 0, "a segment is a whole number of 8-column blocks");
+#ifndef NSOF_X_SEG0
+#define NSOF_X_SEG0 96
+#endif
+    static constexpr int SEG0 = NSOF_X_SEG0, SEG1 = SW - SEG0;   // the strip's two scan segments (see x_scanner_loop)
+    static_assert(SEG0 % 8 == 0 && SEG1 % 8 == 0 && SEG0 >= SEG1 && SEG1 > 0, "segments: whole 8-column blocks, the left one not shorter");
     static constexpr int SVW = SW + 2;                      // doubles per (row, plane) of D / g (even: 16-byte rows)
     static constexpr int WAVES = NCW + 1 + 2 * NB + 1;
     static constexpr int THREADS = 64 * WAVES;
@@ -346,7 +349,7 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
     // The scanner works on the strip's two halves a step apart (segment 1 of step s in the window after segment 0 of step
     // s), so the threads of the right half publish their D one window late (kept in registers meanwhile) and solve one
     // window late: lag = 1.
-    const int lag = j >= G::SEG ? 1 : 0;
+    const int lag = j >= G::SEG0 ? 1 : 0;
     XT_DECL(xt && j == 0);
     double Dreg[4][5];
     // step s: four more rows enter the windows of this thread's two columns -> Dreg
@@ -437,7 +440,7 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
         XT_MARK(6);    // wait at the barrier
         const int step = t - seg;
         const double Sleft = __shfl(Smid, lane >= 20 ? lane - 20 : lane);
-        d2* row = reinterpret_cast<d2*>(sv + (step & 1) * (G::SV1_BYTES / sizeof(double)) + l * SVW + seg * G::SEG);
+        d2* row = reinterpret_cast<d2*>(sv + (step & 1) * (G::SV1_BYTES / sizeof(double)) + l * SVW + seg * G::SEG0);
         if (lane < 40 && step >= 0 && step < nimg) {
             double S;
             if (seg) {
@@ -458,9 +461,10 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
             // loads (LDS operations of a wave complete in order).  The compiler's own schedule of this loop waited for
             // every store (its loop-header wait is the merge of two different queue states).  Reads past the strip's last
             // block land in the spare doubles / the next row and are not used.
-            {
-                unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)row;
-                int nrem = (ncols >> 3) - 1;   // blocks after the first
+            // blocks [b0, b0 + nb) of this lane's row
+            auto scan_blocks = [&](int b0, int nb) {
+                unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(row + 4 * b0);
+                int nrem = nb - 1;   // blocks after the first
                 asm volatile(
                 "ds_read_b128 v[64:67], %[a]\n\t"
                 "ds_read_b128 v[68:71], %[a] offset:16\n\t"
@@ -563,8 +567,11 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
                     : [S] "+v"(S), [a] "+v"(a), [n] "+s"(nrem)
                     :
                     : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-
-            }
+            };
+            // both segments run the stream of the shorter one together; the rest of the longer (left) one follows
+            const int nb0 = ncols >> 3, nba = nb0 < G::SEG1 / 8 ? nb0 : G::SEG1 / 8;
+            scan_blocks(0, nba);
+            if (nb0 > nba && !seg) scan_blocks(nba, nb0 - nba);
             if (seg) cb[(step & 1) * 20 + l] = S;   // the row-end sums: the I/O wave hands them to the right neighbour
             else Smid = S;
         }
@@ -650,7 +657,7 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
         float2* Fout = reinterpret_cast<float2*>(flow_out) + (HET ? 0 : (size_t)pair * plane);
         x_consumer_loop<MH>(ring, sv, vinit, Fout, fpitch, W, H, x0, tid, nimg, 1. / (block_size * block_size), strip == 0, xt);
     } else if (wave == G::NCW) {
-        const int ncols = min(G::SEG, (W - x0 + 7) & ~7);   // columns of a segment's instruction stream
+        const int ncols = min(G::SEG0, (W - x0 + 7) & ~7);   // columns of the left segment
         x_scanner_loop<MH>(sv, vinit, cb, strip > 0, nimg, ncols, tid & 63, xt);
     } else {
         // producers: waves NCW+1 .. NCW+NB rows 0,1 of blocks 0..NB-1; wave NCW+NB+1 the remainder; then rows 2,3

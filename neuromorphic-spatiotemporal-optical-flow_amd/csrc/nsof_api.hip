@@ -151,13 +151,17 @@ void* nsof_pinned_alloc(int device, size_t bytes)
     void* p = nullptr;
     const int node = nsof_gpu_numa_node(device);
     bool policy = false;
-    if (node >= 0 && node < 1024) {
+    // the calling thread's own policy (an application may run under numactl --membind / --interleave): saved and restored
+    int old_mode = 0;
+    unsigned long old_mask[16] = {0};
+    const bool have_old = syscall(SYS_get_mempolicy, &old_mode, old_mask, 8 * sizeof(old_mask) + 1, nullptr, 0) == 0;
+    if (node >= 0 && node < 1024 && have_old) {
         unsigned long mask[16] = {0};
         mask[node / (8 * sizeof(unsigned long))] = 1ul << (node % (8 * sizeof(unsigned long)));
         policy = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 8 * sizeof(mask) + 1) == 0;
     }
     hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, policy ? hipHostMallocNumaUser : hipHostMallocDefault);
-    if (policy) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0);
+    if (policy) (void)syscall(SYS_set_mempolicy, old_mode, old_mode == 0 ? nullptr : old_mask, old_mode == 0 ? 0 : 8 * sizeof(old_mask) + 1);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;

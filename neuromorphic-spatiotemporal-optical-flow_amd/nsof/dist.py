@@ -88,26 +88,59 @@ def run_sharded(prev_all, next_all, n_total, shape, device, compute, src=0):
     return gather_flows(flow, n_total, dst=src)
 
 
-def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, chunk=32, src=0):
+def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, chunk=32, src=0, compute_into=None,
+                           src_share=1.0, stats=None):
     """scatter -> compute -> gather as a three-stage pipeline over chunks of every rank's shard, point to point
-    (``dist.batch_isend_irecv``: ncclSend/ncclRecv pairs under RCCL, one xGMI link per peer) instead of the padded
-    ``dist.scatter`` / ``dist.gather`` through rank ``src``: in round k the frames of chunk k travel to the peers while
-    chunk k-1 computes and the flow of chunk k-2 travels back, so the links and the GPUs are busy together and no rank
-    ever holds more than two chunks of staging.  Rank ``src`` computes its own shard in place.
+    (``dist.batch_isend_irecv``: ncclSend/ncclRecv pairs under RCCL, one xGMI link per peer, all peers of a round in one
+    group) instead of the padded ``dist.scatter`` / ``dist.gather`` through rank ``src``: in round k the frames of chunk k
+    travel to the peers while chunk k-1 computes and the flow of chunk k-2 travels back, so the links and the GPUs are
+    busy together.  Staging is allocated ONCE (two frame and two flow buffers of one chunk per peer rank; rank ``src``
+    receives straight into the result) -- nothing is allocated inside the rounds when ``compute_into`` is given.
 
-    ``prev_all`` / ``next_all``: uint8 [n_total, H, W] on rank ``src`` (ignored elsewhere); ``compute(prev, next) ->
-    float32 [n, H, W, 2]`` on ``device``.  Returns float32 [n_total, H, W, 2] on rank ``src``, None elsewhere."""
+    ``prev_all`` / ``next_all``: uint8 [n_total, H, W] on rank ``src`` (ignored elsewhere).
+    ``compute(prev, next) -> float32 [n, H, W, 2]`` on ``device``, or ``compute_into(prev, next, out)`` writing a
+    preallocated ``out``.  STREAM ORDER: the result must be ordered on torch's CURRENT stream -- RCCL's ``wait()`` orders
+    only that stream, so a compute that runs on a private stream (a default ``nsof.Context`` owns one) must either be
+    switched to torch's stream (``ctx.set_stream(torch.cuda.current_stream().cuda_stream)``, what bench.py does) or
+    synchronise before it returns (``ctx.synchronize()``).
+    ``src_share``: rank ``src`` is also the sink of every flow field (7 peers x 16.6 MB per 1080p pair); a share below 1
+    gives it proportionally fewer pairs than a peer (0 = it only distributes and collects).
+    ``stats`` (dict): receives backend, world size, rounds and bytes moved.
+    Returns float32 [n_total, H, W, 2] on rank ``src``, None elsewhere."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    bounds = shard_bounds(n_total, world)
     h, w = shape
+    if world > 1 and src_share != 1.0:
+        # weights: peers 1, src src_share
+        wsum = (world - 1) + max(0.0, float(src_share))
+        cnt = [int(n_total * ((max(0.0, float(src_share)) if r == src else 1.0) / wsum)) for r in range(world)]
+        rest = n_total - sum(cnt)
+        order = [r for r in range(world) if r != src] + [src]
+        for i in range(rest):
+            cnt[order[i % world]] += 1
+        bounds, lo = [], 0
+        for r in range(world):
+            bounds.append((lo, lo + cnt[r]))
+            lo += cnt[r]
+    else:
+        bounds = shard_bounds(n_total, world)
     chunks = [[(c, min(c + chunk, hi)) for c in range(lo, hi, chunk)] for lo, hi in bounds]   # per rank: [(a, b)]
-    rounds = max(len(c) for c in chunks)
+    rounds = max([len(c) for c in chunks] + [0])
     out = torch.empty((n_total, h, w, 2), dtype=torch.float32, device=device) if rank == src else None
-    frames = [None, None]      # peers: double-buffered (prev, next) chunk
-    flows = [None, None]       # peers: double-buffered flow chunk
     my = chunks[rank]
+    frames = flows = None
+    if rank != src and my:
+        cap = max(b - a for a, b in my)
+        frames = [torch.empty((2, cap, h, w), dtype=torch.uint8, device=device) for _ in range(2)]
+        flows = [torch.empty((cap, h, w, 2), dtype=torch.float32, device=device) for _ in range(2)]
+
+    def run(pv, nx, dst):
+        if compute_into is not None:
+            compute_into(pv, nx, dst)
+        else:
+            dst.copy_(compute(pv, nx))
+
     for k in range(rounds + 2):
-        ops, post = [], []
+        ops = []
         # stage A: frames of chunk k leave rank src
         if rank == src:
             for r in range(world):
@@ -117,29 +150,34 @@ def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, 
                     ops.append(dist.P2POp(dist.isend, next_all[a:b].to(device).contiguous(), r))
         elif k < len(my):
             a, b = my[k]
-            buf = torch.empty((2, b - a, h, w), dtype=torch.uint8, device=device)
-            frames[k & 1] = buf
-            ops.append(dist.P2POp(dist.irecv, buf[0], src))
-            ops.append(dist.P2POp(dist.irecv, buf[1], src))
-        # stage C: flow of chunk k-2 returns to rank src
+            buf = frames[k & 1]
+            ops.append(dist.P2POp(dist.irecv, buf[0, :b - a], src))
+            ops.append(dist.P2POp(dist.irecv, buf[1, :b - a], src))
+        # stage C: flow of chunk k-2 returns to rank src (straight into the result)
         if rank == src:
             for r in range(world):
                 if r != src and 0 <= k - 2 < len(chunks[r]):
                     a, b = chunks[r][k - 2]
                     ops.append(dist.P2POp(dist.irecv, out[a:b], r))
         elif 0 <= k - 2 < len(my):
-            ops.append(dist.P2POp(dist.isend, flows[k & 1], src))
+            a, b = my[k - 2]
+            ops.append(dist.P2POp(dist.isend, flows[k & 1][:b - a], src))
         reqs = dist.batch_isend_irecv(ops) if ops else []
         # stage B: chunk k-1 computes while the copies above are in flight
         if 0 <= k - 1 < len(my):
             a, b = my[k - 1]
             if rank == src:
-                out[a:b] = compute(prev_all[a:b].to(device), next_all[a:b].to(device))
+                run(prev_all[a:b].to(device), next_all[a:b].to(device), out[a:b])
             else:
                 f = frames[(k - 1) & 1]
-                flows[(k - 1) & 1] = compute(f[0], f[1]).contiguous()
+                run(f[0, :b - a], f[1, :b - a], flows[(k - 1) & 1][:b - a])
         for q in reqs:
             q.wait()
+    if stats is not None:
+        moved = sum(b - a for r in range(world) if r != src for a, b in chunks[r])
+        stats.update(backend=dist.get_backend(), world_size=world, rank=rank, rounds=rounds, chunk_pairs=chunk,
+                     pairs_per_rank=[hi - lo for lo, hi in bounds], pairs_moved=moved,
+                     bytes_moved=moved * (2 * h * w + 8 * h * w))
     return out
 
 

@@ -47,6 +47,18 @@ def _worker(rank, world, port, n_total, ret):
         assert torch.equal(out2, out)
     else:
         assert out2 is None
+    # preallocated staging + compute_into; the sink rank with a smaller share / no share of the pairs; the stats record
+    for share in (1.0, 0.5, 0.0):
+        st = {}
+        out3 = nd.run_sharded_overlapped(prev, nxt, n_total, (h, wd), "cpu", None, chunk=3, src_share=share, stats=st,
+                                         compute_into=lambda p_, q_, o_: o_.copy_(_fake_flow(p_, q_)))
+        assert st["backend"] == "gloo" and st["world_size"] == world and sum(st["pairs_per_rank"]) == n_total
+        if share == 0.0 and world > 1:
+            assert st["pairs_per_rank"][0] == 0 and st["pairs_moved"] == n_total
+        if rank == 0:
+            assert torch.equal(out3, out), share
+        else:
+            assert out3 is None
     t = nd.max_over_ranks(1.0 + rank)
     assert t == float(world)
     if rank == 0:

@@ -204,6 +204,30 @@ def test_work_list_vs_oracle_and_canvas_paste(nsof_lib, ctx, oracle):
 
 
 @pytest.mark.gpu
+def test_pipelined_entry_drains_on_error(nsof_lib, ctx, oracle):
+    """An error in the middle of the pipelined host entry (injected after chunk 1 of several, NSOF_PIPE_FAIL_AFTER_CHUNK)
+    must not leave uploads / downloads in flight: the call raises, the caller's arrays can be dropped at once, and the
+    next call on the same context works and is correct."""
+    from nsof.errors import NsofError
+    nsof = nsof_lib
+    p = nsof.FarnebackParams(*A)
+    pairs = _crops(9, SHAPES[:8])
+    os.environ["NSOF_PIPE_CHUNK_MB"] = "1"
+    os.environ["NSOF_PIPE_FAIL_AFTER_CHUNK"] = "1"
+    try:
+        with pytest.raises(NsofError, match="injected failure"):
+            nsof.farneback_pairs(pairs, p, ctx=ctx)
+    finally:
+        del os.environ["NSOF_PIPE_FAIL_AFTER_CHUNK"]
+    try:
+        got = nsof.farneback_pairs(pairs, p, ctx=ctx)
+    finally:
+        del os.environ["NSOF_PIPE_CHUNK_MB"]
+    for (a, b), f in zip(pairs, got):
+        assert np.array_equal(f, oracle.farneback(np.ascontiguousarray(a), np.ascontiguousarray(b), *A))
+
+
+@pytest.mark.gpu
 def test_work_list_device_crops(nsof_lib, ctx, torch_dev):
     """Device-resident twin: crops of frames already in HBM, flows into crops of a device canvas."""
     import torch
