@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel-trace + stats of the headline bench (run on the GPU box via gpurun).
 # usage: bash scripts/prof_kernel_trace.sh <tag> [bench args...]
+# (pass --no-config5 --e2e-pairs 0 --no-fast-leg --no-param-legs to profile the headline steps alone: the kernel averages
+#  then cover exactly the (steps + warmup) x 12 launches the bench line's roofline is computed from)
 set -e
 TAG=${1:-r01}; shift || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -11,7 +11,7 @@ export NSOF_SKIP_BUILD=1
 mkdir -p $REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $REPO/gpurun_out/pmcb_${TAG}_$C -- \
+  rocprofv3 --pmc $C --kernel-include-regex "k_(iterate|polyexp|flow_upsample|prep)" --output-format csv -d $REPO/gpurun_out/pmcb_${TAG}_$C -- \
       python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-config5 --e2e-pairs 0 --no-fast-leg --no-param-legs \
       "$@" > $REPO/gpurun_out/pmcb_${TAG}_$C.json 2> $REPO/gpurun_out/pmcb_${TAG}_$C.log
   if grep -q "Could not construct profile cfg\|exceeds the capabilities" $REPO/gpurun_out/pmcb_${TAG}_$C.log; then
@@ -22,7 +22,7 @@ python3 - "$REPO" "$TAG" <<'PY'
 import csv, glob, json, re, sys, collections
 repo, tag = sys.argv[1], sys.argv[2]
 line = json.loads(open(f"{repo}/gpurun_out/pmcb_{tag}_FETCH_SIZE.json").read().strip().splitlines()[-1])
-fam = {"k_iterate_q": "iterate", "k_polyexp_rs": "polyexp", "k_polyexp": "polyexp", "k_flow_upsample_walk": "flow_upsample"}
+fam = {"k_iterate_x": "iterate", "k_iterate_q": "iterate_fast", "k_polyexp_rs": "polyexp", "k_polyexp": "polyexp", "k_flow_upsample_walk": "flow_upsample"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{repo}/gpurun_out/pmcb_{tag}_{c}/**/*counter_collection.csv", recursive=True)[0]
@@ -37,7 +37,7 @@ out = {"_doc": "HBM bytes per launch from rocprofv3 PMC over bench.py's OWN laun
                "/opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced streaming reads, "
                "so it is doubled; WRITE_SIZE is exact for 16-B streaming stores.  bench.py multiplies its algorithmic "
                "bytes per launch by traffic_over_algorithmic and labels the result as an estimate.",
-       "round": 2, "kernels": {}}
+       "round": 3, "kernels": {}}
 for name, key in (("iterate", "roofline"), ("polyexp", "roofline_polyexp")):
     v = acc.get(name)
     if not v or not v["FETCH_SIZE"] or not v["WRITE_SIZE"] or not line.get(key):
