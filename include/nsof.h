@@ -264,6 +264,9 @@ int nsof_accum_read_snapshots(nsof_accum* acc, int which, float* out, int64_t ma
  * of the current state when snapshot < 0.  Same values as dividing the downloaded float32 resistance map on the host
  * (max of v_ds/R = v_ds / min R); only rows x cols doubles cross PCIe instead of the whole surface. */
 int nsof_accum_block_current(nsof_accum* acc, int which, int64_t snapshot, int memsize, double v_ds, double* out);
+/* The same map written to DEVICE memory (d_out: rows x cols doubles), asynchronous on the context's stream: the input of
+ * nsof_roi_from_surface_dev. */
+int nsof_accum_block_current_dev(nsof_accum* acc, int which, int64_t snapshot, int memsize, double v_ds, double* d_out);
 /* Frame-driven variant of the same device ODE (simulation/simulationcode_v4_transistor_uav.m:146-227,332-347),
  * float64: imgs = HOST compressed frames [n_frames][H][W] in [0,1]; per frame pair the drive voltage comes
  * from |a-b|*256 through the piecewise map (th1, th2) and modulatefunc, followed by n_sub_steps Euler sub-steps
@@ -287,6 +290,17 @@ int64_t nsof_accum_slice_bounds(const int64_t* t, int64_t n, int64_t slice_us, i
 int nsof_roi_from_surface(const double* current, int rows, int cols, int frame_w, int frame_h, int memsize, int thres,
                           int extend_left, int extend_right, int extend_upper, int extend_lower, int connectivity,
                           int flag, int* rects, int max_rects);
+
+/* Device twin of nsof_roi_from_surface (replaces optical_flow_seg.py:115-121,211-252 for maps that are already in HBM):
+ * n_maps gating maps at once, one wavefront each -- d_current: device currents, double, map k at d_current + k*map_stride
+ * (rows x cols cells, at most 64 x 64); gray map, threshold, connected components in raster order (bit-parallel flood
+ * fill), rectangles as above.  d_counts[k] = number of rectangles of map k (may exceed max_rects; only the first max_rects
+ * are stored), d_rects[k][max_rects][4] = (x0, y0, x1, y1); d_gray (optional, may be NULL): the 8-bit gating maps
+ * [n_maps][rows][cols].  All DEVICE memory; asynchronous on the context's stream. */
+int nsof_roi_from_surface_dev(nsof_ctx* ctx, const double* d_current, int n_maps, size_t map_stride, int rows, int cols,
+                              int frame_w, int frame_h, int memsize, int thres, int extend_left, int extend_right,
+                              int extend_upper, int extend_lower, int connectivity, int flag, int max_rects, int* d_counts,
+                              int* d_rects, unsigned char* d_gray);
 
 /* ---- next: motion-segmentation head on the flow field --------------------- */
 /* Replaces, in /root/reference/optical_flow_seg.py, the chain

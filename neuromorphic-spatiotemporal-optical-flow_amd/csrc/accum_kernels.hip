@@ -988,6 +988,23 @@ extern "C" int nsof_accum_block_current(nsof_accum* a, int which, int64_t snapsh
     return NSOF_OK;
 }
 
+// Device twin: the map goes to DEVICE memory (d_out, rows x cols doubles), nothing is synchronised -- the input of
+// nsof_roi_from_surface_dev, so that events -> surface -> ROI rectangles never visits the host.
+extern "C" int nsof_accum_block_current_dev(nsof_accum* a, int which, int64_t snapshot, int memsize, double v_ds, double* d_out)
+{
+    if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || memsize < 1 || memsize > a->W || memsize > a->H || !(v_ds > 0))
+        return NSOF_EINVAL;
+    if (snapshot >= a->snap_count) return nsof_set_error(a->ctx, NSOF_EINVAL, "snapshot %lld of %lld", (long long)snapshot, (long long)a->snap_count);
+    nsof_ctx* ctx = a->ctx;
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const int rows = a->H / memsize, cols = a->W / memsize;
+    const float* src = snapshot < 0 ? a->w[which] : a->snap[which] + (size_t)snapshot * a->npx;
+    hipLaunchKernelGGL(k_block_min_resistance, dim3(cols, rows), dim3(256), 0, ctx->stream, src, snapshot < 0 ? 1 : 0, a->W,
+                       memsize, cols, (float)(-std::log(ROFF / RON)), v_ds, d_out);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
 extern "C" int nsof_accum_read_snapshots(nsof_accum* a, int which, float* out, int64_t max_count)
 {
     if (!a || which < 0 || which > (a->split ? 1 : 0)) return NSOF_EINVAL;

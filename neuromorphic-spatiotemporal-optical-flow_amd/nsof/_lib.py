@@ -79,9 +79,11 @@ SIGNATURES = {
     "nsof_accum_snapshot_count": (_i64, [_vp]),
     "nsof_accum_read_snapshots": (_i, [_vp, _i, _vp, _i64]),
     "nsof_accum_block_current": (_i, [_vp, _i, _i64, _i, _d, _vp]),
+    "nsof_accum_block_current_dev": (_i, [_vp, _i, _i64, _i, _d, _vp]),
     "nsof_accum_frames_f64": (_i, [_vp, _vp, _i, _i, _i, _d, _i, _d, _d, _vp, _vp]),
     "nsof_accum_slice_bounds": (_i64, [_vp, _i64, _i64, _vp, _i64]),
     "nsof_roi_from_surface": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "nsof_roi_from_surface_dev": (_i, [_vp, _vp, _i, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "nsof_structuring_element": (_i, [_i, _i, _i, _vp]),
     "nsof_morph_binary_u8_dev": (_i, [_vp, _i, _vp, _pd, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _pd]),
     "nsof_motion_mask_dev": (_i, [_vp, _vp, _pd, _i, _i, _d, _i, _i, _vp, _pd]),

@@ -206,6 +206,12 @@ class Accumulator:
                                                               float(v_ds), out.ctypes.data), "accum_block_current")
         return out
 
+    def block_current_dev(self, memsize, d_out, which=0, snapshot=-1, v_ds=1.0):
+        """``block_current`` written to DEVICE memory (``d_out``: torch float64 tensor / address of
+        (H // memsize) * (W // memsize) doubles), asynchronous: the input of ``gating.roi_from_surface_dev``."""
+        self.ctx.check(self.ctx._lib.nsof_accum_block_current_dev(self._p, int(which), int(snapshot), int(memsize),
+                                                                  float(v_ds), dev_ptr(d_out)), "accum_block_current_dev")
+
     def state(self, which=0):
         """-> dict(w float32 [H][W], next_ok int64 [H][W], slice_counter) -- everything a resume needs."""
         w = np.empty((self.H, self.W), np.float32)

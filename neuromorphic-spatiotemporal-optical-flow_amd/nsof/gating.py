@@ -263,3 +263,38 @@ def roi_from_surface(current, frame_hw, cfg):
         if n <= cap:
             return [tuple(rects[4 * i:4 * i + 4]) for i in range(n)]
         cap = n
+
+
+def roi_from_surface_dev(d_current, n_maps, map_hw, frame_hw, cfg, max_rects=32, ctx=None, want_gray=False, map_stride=None):
+    """Device twin of ``roi_from_surface`` for ``n_maps`` gating maps already in HBM (``d_current``: torch float64 tensor
+    / device address, map k at ``+ k * map_stride`` doubles, default rows * cols): one wavefront per map forms the gray
+    map, thresholds it, labels the connected components in raster order and writes the crop rectangles
+    (``nsof_roi_from_surface_dev``; optical_flow_seg.py:115-121, 211-252).  Returns device tensors
+    ``(counts int32 [n_maps], rects int32 [n_maps][max_rects][4][, gray uint8 [n_maps][rows][cols]])`` -- nothing is
+    synchronised or copied to the host; ``rects_to_host`` fetches them in one small copy."""
+    import torch
+
+    from .context import default_context, dev_ptr
+    ctx = ctx or default_context()
+    rows, cols = map_hw
+    h, w = frame_hw
+    dev = torch.device("cuda", ctx.device)
+    counts = torch.empty((n_maps,), dtype=torch.int32, device=dev)
+    rects = torch.empty((n_maps, max_rects, 4), dtype=torch.int32, device=dev)
+    gray = torch.empty((n_maps, rows, cols), dtype=torch.uint8, device=dev) if want_gray else None
+    ctx.check(ctx._lib.nsof_roi_from_surface_dev(
+        ctx.ptr, dev_ptr(d_current), int(n_maps), int(rows * cols if map_stride is None else map_stride), int(rows), int(cols),
+        int(w), int(h), cfg.MEMSIZE, cfg.THRES, cfg.EXTEND_WIDTH_LEFT, cfg.EXTEND_WIDTH_RIGHT, cfg.EXTEND_HEIGHT_UPPER,
+        cfg.EXTEND_HEIGHT_LOWER, cfg.CONNECT, cfg.FLAG, int(max_rects), dev_ptr(counts), dev_ptr(rects),
+        dev_ptr(gray) if want_gray else None), "roi_from_surface_dev")
+    return (counts, rects, gray) if want_gray else (counts, rects)
+
+
+def rects_to_host(counts, rects, ctx=None):
+    """``[[(x0, y0, x1, y1), ...] per map]`` from the device tables of ``roi_from_surface_dev`` (one small D2H copy)."""
+    from .context import default_context
+    (ctx or default_context()).synchronize()
+    c, r = counts.cpu().numpy(), rects.cpu().numpy()
+    if (c > r.shape[1]).any():
+        raise ValueError(f"a gating map has {int(c.max())} components; max_rects was {r.shape[1]}")
+    return [[tuple(int(v) for v in r[k, i]) for i in range(int(c[k]))] for k in range(len(c))]

@@ -23,15 +23,46 @@ def surface_to_block_current(resistance, memsize, v_ds=1.0):
 
 
 def events_to_rois(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slice_us=1000, active_v=-6.0,
-                   silent_v=0.0, snapshot_every=33, ctx=None):
+                   silent_v=0.0, snapshot_every=33, ctx=None, max_rects=32):
     """Run the accumulator over the stream and return, for every snapshot, the gating map and its ROI rectangles
-    (x0, y0, x1, y1) in sensor pixels."""
+    (x0, y0, x1, y1) in sensor pixels.  Everything between the event upload and the result stays in HBM: the block maxima of
+    the device current of every snapshot (``Accumulator.block_current_dev``), then ONE launch of the gating kernel over
+    all snapshots (``gating.roi_from_surface_dev``: gray map, threshold, connected components, rectangles -- one
+    wavefront per snapshot); the rectangle table and the tiny gray maps come back in one copy at the end."""
+    import torch
+
+    from .context import default_context
+    ctx = ctx or default_context()
+    H, W = sensor_hw  # noqa: N806
+    idx = slice_index_array(t, slice_us)
+    rows, cols = H // cfg.MEMSIZE, W // cfg.MEMSIZE
+    acc = Accumulator(H, W, version, polarity, active_v, silent_v, ctx=ctx)
+    try:
+        acc.step(x, y, p, t, idx, snap_every=snapshot_every)
+        n = acc.snapshot_count()
+        if n == 0:
+            return []
+        cur = torch.empty((n, rows, cols), dtype=torch.float64, device=torch.device("cuda", ctx.device))
+        for k in range(n):
+            acc.block_current_dev(cfg.MEMSIZE, cur[k], snapshot=k)
+        counts, rects, gray = gating.roi_from_surface_dev(cur, n, (rows, cols), (H, W), cfg, max_rects=max_rects, ctx=ctx,
+                                                          want_gray=True)
+        lists = gating.rects_to_host(counts, rects, ctx=ctx)
+        g = gray.cpu().numpy()
+    finally:
+        acc.close()
+    return [(g[k], lists[k]) for k in range(n)]
+
+
+def events_to_rois_host(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slice_us=1000, active_v=-6.0,
+                        silent_v=0.0, snapshot_every=33, ctx=None):
+    """The same through the host-side mirror of the reference's gating (``gating.connectedComponentsWithStats`` on the
+    downloaded block currents): kept as the independent path the device kernel is tested against."""
     H, W = sensor_hw  # noqa: N806
     idx = slice_index_array(t, slice_us)
     acc = Accumulator(H, W, version, polarity, active_v, silent_v, ctx=ctx)
     try:
         acc.step(x, y, p, t, idx, snap_every=snapshot_every)
-        # block maxima of the current are reduced on the GPU: rows x cols doubles per snapshot cross PCIe, not H x W floats
         blocks = [acc.block_current(cfg.MEMSIZE, snapshot=k) for k in range(acc.snapshot_count())]
     finally:
         acc.close()

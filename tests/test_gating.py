@@ -1,6 +1,7 @@
 """ROI gating harness: host logic on CPU with the reference's own gating data
 (tests/golden/gating_maps.json = slices of data/*/constructed_3D_matrix.mat), flow calls on the GPU."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -233,3 +234,93 @@ def test_float32_canvas_option(nsof_lib, maps, oracle):
         out.append(nsof_lib.opticalFlow3D(mem, mem, a, b, 8, 8, cfg, flow_fn=far)[0])
     assert out[0].dtype == np.float64 and out[1].dtype == np.float32 and np.array_equal(out[0], out[1])
     assert np.abs(out[0]).max() > 0
+
+
+@pytest.mark.gpu
+def test_device_gating_equals_reference_gating_on_all_stacks(nsof_lib, ctx):
+    """nsof_roi_from_surface_dev (one wavefront per gating map: gray map, threshold, connected components by bit-parallel
+    flood fill in raster order, scaled / extended rectangles) against the Python mirror of opticalFlow3D's gating
+    (optical_flow_seg.py:115-121, 211-252) on EVERY slice of the reference's five constructed_3D_matrix.mat stacks, both
+    FLAG settings, connectivity 4 and 8: rectangles equal as integers, in the same order; gray maps byte-identical."""
+    import torch
+    from nsof import gating
+    from nsof import workload as wl
+    stacks = np.load(os.path.join(os.path.dirname(__file__), "golden", "gating_stacks.npz"))
+    dev = torch.device("cuda", ctx.device)
+    n = 0
+    for name, (h, w, _) in wl.DATASET_FRAMES.items():
+        st = np.ascontiguousarray(np.moveaxis(stacks[name], 2, 0))           # [slices][rows][cols]
+        d = torch.from_numpy(st).to(dev)
+        torch.cuda.synchronize()
+        for flag in (1, 2):
+            for conn in (4, 8):
+                cfg = gating.dataset_config(name, FLAG=flag, CONNECT=conn)
+                counts, rects, gray = gating.roi_from_surface_dev(d, st.shape[0], st.shape[1:], (h, w), cfg, ctx=ctx,
+                                                                  want_gray=True)
+                got = gating.rects_to_host(counts, rects, ctx=ctx)
+                g = gray.cpu().numpy()
+                for k in range(st.shape[0]):
+                    assert np.array_equal(g[k], gating.current_to_gray(st[k])), (name, k)
+                    want = gating.roi_from_surface(st[k], (h, w), cfg)      # host C mirror (itself == Python, test_workload)
+                    assert got[k] == want, (name, flag, conn, k, got[k], want)
+                    n += len(want)
+    assert n > 1000
+
+
+@pytest.mark.gpu
+def test_device_gating_random_maps_up_to_64x64(nsof_lib, ctx):
+    """Random maps of every size class up to 64 x 64 cells (snakes, rings, checkerboards included), 4- and 8-connectivity,
+    more components than max_rects -> counts report the true number."""
+    import torch
+    from nsof import gating
+    rng = np.random.default_rng(3)
+    dev = torch.device("cuda", ctx.device)
+    for (rows, cols, dens) in [(1, 1, 1.0), (4, 4, 0.5), (13, 24, 0.3), (32, 32, 0.55), (64, 64, 0.45), (64, 17, 0.6), (5, 64, 0.5)]:
+        ms = 7
+        h, w = rows * ms + 3, cols * ms + 5
+        on = rng.random((6, rows, cols)) < dens
+        if rows >= 8 and cols >= 8:          # a snake that needs many flood iterations, and a ring
+            on[0] = False
+            on[0, ::2, :] = True
+            for r in range(1, rows, 2):
+                on[0, r, (cols - 1) if (r // 2) % 2 == 0 else 0] = True
+            on[1] = False
+            on[1, 1:-1, 1] = on[1, 1:-1, -2] = on[1, 1, 1:-1] = on[1, -2, 1:-1] = True
+            on[2] = (np.add.outer(np.arange(rows), np.arange(cols)) % 2) == 0
+        cur = np.where(on, 1e-5, 1e-9)      # gray 255 vs 68
+        d = torch.from_numpy(cur).to(dev)
+        torch.cuda.synchronize()
+        for flag in (1, 2):
+            for conn in (4, 8):
+                cfg = gating.GatingConfig(MEMSIZE=ms, THRES=200, FLAG=flag, CONNECT=conn, EXTEND_HEIGHT_UPPER=2,
+                                          EXTEND_HEIGHT_LOWER=3, EXTEND_WIDTH_LEFT=1, EXTEND_WIDTH_RIGHT=4)
+                want = [gating.roi_from_surface(cur[k], (h, w), cfg) for k in range(6)]
+                cap = max(1, max(len(v) for v in want))
+                counts, rects = gating.roi_from_surface_dev(d, 6, (rows, cols), (h, w), cfg, max_rects=cap, ctx=ctx)
+                assert gating.rects_to_host(counts, rects, ctx=ctx) == want, (rows, cols, flag, conn)
+                if cap > 1:                                      # too little room: the count is still the true one
+                    c2, r2 = gating.roi_from_surface_dev(d, 6, (rows, cols), (h, w), cfg, max_rects=1, ctx=ctx)
+                    ctx.synchronize()
+                    assert c2.cpu().numpy().tolist() == [len(v) for v in want]
+                    first = r2.cpu().numpy()[:, 0]
+                    assert all(tuple(int(q) for q in first[k]) == v[0] for k, v in enumerate(want) if v)
+
+
+@pytest.mark.gpu
+def test_events_to_rois_device_path_equals_host_path(nsof_lib, ctx):
+    """pipeline.events_to_rois (accumulator -> block currents -> gating kernel, all in HBM, one small copy at the end)
+    returns what the host-side mirror of the reference's gating returns on the downloaded block currents."""
+    from nsof import gating, pipeline, synth
+    H, W = 240, 320   # noqa: N806
+    x, y, p, t = synth.make_events(7, W, H, n_background=3000, duration_us=160_000, box=(40, 30), speed_pps=500.0)
+    for flag in (1, 2):
+        cfg = gating.GatingConfig(MEMSIZE=20, EXTEND_HEIGHT_UPPER=10, EXTEND_HEIGHT_LOWER=10, EXTEND_WIDTH_LEFT=10,
+                                  EXTEND_WIDTH_RIGHT=10, THRES=240, FLAG=flag, farneback_params=nsof_lib.farneback.PARAMS_A)
+        a = pipeline.events_to_rois(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5, snapshot_every=40, ctx=ctx)
+        b = pipeline.events_to_rois_host(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5, snapshot_every=40, ctx=ctx)
+        assert len(a) == len(b) == 4
+        for (ga, ra), (gb, rb) in zip(a, b):
+            assert np.array_equal(ga, gb)
+            want = rb if flag == 1 else ([(min(r[0] for r in rb), min(r[1] for r in rb), max(r[2] for r in rb), max(r[3] for r in rb))] if rb else [])
+            assert ra == want
+        assert any(len(r) for _, r in a)
