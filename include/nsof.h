@@ -75,7 +75,13 @@ int nsof_synchronize(nsof_ctx* ctx);
  * decimal at many pixels with 3x3 / 4x4 windows (DESIGN.md section 5.1 has the soak counts).  Off by default so that a
  * pair's flow does not depend on the batch it was part of.  Values 2 and 3 are rejected.  Environment default:
  * NSOF_ROW_BANDS. */
-enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3 };
+/* NSOF_OPT_PYR_FMA (default 0): the arithmetic-variant twin of the pyramid stages.  0 = the float Gaussian blur and the
+ * bilinear resamples (pyramid levels, flow resize between levels) round every product and every sum, as the library's
+ * generic C++ code does; 1 = the same taps in the same order with one fused multiply-add per tap / blend, as an AVX2+FMA3
+ * build of the library's vector loops contracts them.  Which of the two a given cv2 wheel executes cannot be pinned in
+ * this image (DESIGN.md section 2 states how far the flow moves between them); both equal their CPU restatement
+ * (oracle build of the same switch) bit for bit.  Environment default: NSOF_PYR_FMA. */
+enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3, NSOF_OPT_PYR_FMA = 4 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);
 

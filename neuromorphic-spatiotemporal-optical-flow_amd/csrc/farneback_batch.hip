@@ -194,11 +194,11 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
             const nsof_het_item* ht = tabs + (size_t)k * nh;
             const int nk_items = cnt[k];
             // incoming flow of the level: resample of the coarser level's field (zero for items that start here)
-            if ((rc = nsof_launch_flow_upsample_het(ctx, nk_items, dt, max_w[k], max_h[k], fb[cur], fb[cur ^ 1],
+            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample_het, nk_items, dt, max_w[k], max_h[k], fb[cur], fb[cur ^ 1],
                                                     (float)(1. / p.pyr_scale))))
                 return rc;
             cur ^= 1;
-            if ((rc = nsof_launch_prep_het(ctx, nk_items, dt, ht, k == 0, btaps, dI))) return rc;
+            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_het, nk_items, dt, ht, k == 0, btaps, dI))) return rc;
             if ((rc = nsof_launch_polyexp_het(ctx, nk_items, dt, max_w[k], max_h[k], ptaps, dI, dR))) return rc;
             for (int it = 0; it < p.iterations; it++) {
                 const bool final = k == 0 && it == p.iterations - 1;

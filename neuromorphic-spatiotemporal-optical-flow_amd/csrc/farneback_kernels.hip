@@ -14,6 +14,20 @@
 
 #include "nsof_internal.h"
 
+// This translation unit is compiled twice.  The regular object forms the float Gaussian blur and the bilinear resamples
+// (pyramid levels, flow resize) as the library's generic C++ path does: multiply, round, add, round.  With -DNSOF_PYR_FMA
+// (object farneback_kernels_fma.o) the same taps in the same order are CONTRACTED the way an AVX2+FMA3 build of the
+// library's vector code (v_muladd / v_fma in its separable-filter and resize loops) contracts them: one fused
+// multiply-add per tap / blend, the leading product still rounded -- the arithmetic variant twin of DESIGN.md section 2
+// (context option NSOF_OPT_PYR_FMA).  Only the pyramid-level and flow-resample launchers exist in that object.
+#ifdef NSOF_PYR_FMA
+#define NSOF_MADD(a, b, c) fmaf((a), (b), (c))
+#define NSOF_PYR_NAME(n) n##_fma
+#else
+#define NSOF_MADD(a, b, c) ((a) * (b) + (c))
+#define NSOF_PYR_NAME(n) n
+#endif
+
 namespace {
 
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -62,11 +76,11 @@ template <int KS, typename TapF, typename LoadF>
 __device__ __forceinline__ float row_filter(TapF tk, int ksize, int c, LoadF ld)
 {
     const int ks = KS ? KS : ksize, r = ks >> 1;
-    if (ks == 3) return ld(c) * tk(1) + (ld(c - 1) + ld(c + 1)) * tk(2);
-    if (ks == 5) return ld(c) * tk(2) + (ld(c - 1) + ld(c + 1)) * tk(3) + (ld(c - 2) + ld(c + 2)) * tk(4);
+    if (ks == 3) return NSOF_MADD(ld(c - 1) + ld(c + 1), tk(2), ld(c) * tk(1));
+    if (ks == 5) return NSOF_MADD(ld(c - 2) + ld(c + 2), tk(4), NSOF_MADD(ld(c - 1) + ld(c + 1), tk(3), ld(c) * tk(2)));
     float s = tk(0) * ld(c - r);
 #pragma unroll
-    for (int j = 1; j < ks; j++) s += tk(j) * ld(c - r + j);
+    for (int j = 1; j < ks; j++) s = NSOF_MADD(tk(j), ld(c - r + j), s);
     return s;
 }
 // Column filter at (unreflected) row rr given an accessor of row-filtered values.
@@ -74,10 +88,10 @@ template <int KS, typename TapF, typename LoadF>
 __device__ __forceinline__ float col_filter(TapF tk, int ksize, int rr, LoadF hv)
 {
     const int ks = KS ? KS : ksize, r = ks >> 1;
-    if (ks == 3) return (hv(rr - 1) + hv(rr + 1)) * tk(2) + hv(rr) * tk(1);
+    if (ks == 3) return NSOF_MADD(hv(rr - 1) + hv(rr + 1), tk(2), hv(rr) * tk(1));
     float s = tk(r) * hv(rr);
 #pragma unroll
-    for (int j = 1; j <= r; j++) s += tk(r + j) * (hv(rr + j) + hv(rr - j));
+    for (int j = 1; j <= r; j++) s = NSOF_MADD(tk(r + j), hv(rr + j) + hv(rr - j), s);
     return s;
 }
 
@@ -164,10 +178,10 @@ __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restric
         if (lane == 63 || x + 4 >= W) rgt = rowp[reflect101(xl + 4, W)];
         const float s0 = (float)(v & 0xffu), s1 = (float)((v >> 8) & 0xffu), s2 = (float)((v >> 16) & 0xffu),
                     s3 = (float)(v >> 24), sl = (float)lft, sr = (float)rgt;
-        h[0] = s0 * k0 + (sl + s1) * k1;
-        h[1] = s1 * k0 + (s0 + s2) * k1;
-        h[2] = s2 * k0 + (s1 + s3) * k1;
-        h[3] = s3 * k0 + (s2 + sr) * k1;
+        h[0] = NSOF_MADD(sl + s1, k1, s0 * k0);
+        h[1] = NSOF_MADD(s0 + s2, k1, s1 * k0);
+        h[2] = NSOF_MADD(s1 + s3, k1, s2 * k0);
+        h[3] = NSOF_MADD(s2 + sr, k1, s3 * k0);
     };
     float hm[4], h0[4], hp[4];
     hrow(y0 - 1, hm);
@@ -179,10 +193,10 @@ __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restric
         hrow(y + 1, hp);
         if (live) {
             float4 o;
-            o.x = (hm[0] + hp[0]) * k1 + h0[0] * k0;
-            o.y = (hm[1] + hp[1]) * k1 + h0[1] * k0;
-            o.z = (hm[2] + hp[2]) * k1 + h0[2] * k0;
-            o.w = (hm[3] + hp[3]) * k1 + h0[3] * k0;
+            o.x = NSOF_MADD(hm[0] + hp[0], k1, h0[0] * k0);
+            o.y = NSOF_MADD(hm[1] + hp[1], k1, h0[1] * k0);
+            o.z = NSOF_MADD(hm[2] + hp[2], k1, h0[2] * k0);
+            o.w = NSOF_MADD(hm[3] + hp[3], k1, h0[3] * k0);
             nsof_store_stream4(dst + (size_t)y * W + x, o.x, o.y, o.z, o.w);
         }
 #pragma unroll
@@ -347,9 +361,9 @@ __global__ __launch_bounds__(256) void k_prep_naive(const uint8_t* __restrict__ 
         };
         return col_filter<0>(tk, t.ksize, rr, hv);
     };
-    const float t0 = blur(r0, c0) * a0 + blur(r0, c1) * a1;
-    const float t1 = blur(r1, c0) * a0 + blur(r1, c1) * a1;
-    g.dst[(size_t)dy * wk + dx] = t0 * b0 + t1 * b1;
+    const float t0 = NSOF_MADD(blur(r0, c0), a0, blur(r0, c1) * a1);
+    const float t1 = NSOF_MADD(blur(r1, c0), a0, blur(r1, c1) * a1);
+    g.dst[(size_t)dy * wk + dx] = NSOF_MADD(t0, b0, t1 * b1);
 }
 
 // Resampled level, LDS-tiled: a 32x8 destination tile per 256-thread block.
@@ -450,9 +464,9 @@ __global__ __launch_bounds__(256) void k_prep_tiled(const uint8_t* __restrict__ 
         const float a1 = s_a[tx], a0 = 1.f - a1, b1 = s_b[ty], b0 = 1.f - b1;
         const float* B0 = sB + (2 * ty) * (2 * PREP_TW) + 2 * tx;
         const float* B1 = B0 + 2 * PREP_TW;
-        const float t0 = B0[0] * a0 + B0[1] * a1;
-        const float t1 = B1[0] * a0 + B1[1] * a1;
-        g.dst[(size_t)dy * wk + dx] = t0 * b0 + t1 * b1;
+        const float t0 = NSOF_MADD(B0[0], a0, B0[1] * a1);
+        const float t1 = NSOF_MADD(B1[0], a0, B1[1] * a1);
+        g.dst[(size_t)dy * wk + dx] = NSOF_MADD(t0, b0, t1 * b1);
     }
 }
 
@@ -520,9 +534,9 @@ __global__ __launch_bounds__(256) void k_prep_direct(const uint8_t* __restrict__
         B10 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H0[q]; });
         B11 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H1[q]; });
     }
-    const float t0 = B00 * a0 + B01 * a1;
-    const float t1 = B10 * a0 + B11 * a1;
-    g.dst[(size_t)dy * wk + dx] = t0 * b0 + t1 * b1;
+    const float t0 = NSOF_MADD(B00, a0, B01 * a1);
+    const float t1 = NSOF_MADD(B10, a0, B11 * a1);
+    g.dst[(size_t)dy * wk + dx] = NSOF_MADD(t0, b0, t1 * b1);
 }
 
 // Resampled level, two passes (kernel sizes 9 and 19: levels 2 and 3 of the reference's parameter sets).
@@ -605,9 +619,9 @@ __global__ __launch_bounds__(256) void k_prep_cols(const float* __restrict__ HA,
         B10 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H0[q]; });
         B11 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H1[q]; });
     }
-    const float t0 = B00 * a0 + B01 * a1;
-    const float t1 = B10 * a0 + B11 * a1;
-    out[((size_t)blockIdx.z * hk + dy) * wk + dx] = t0 * b0 + t1 * b1;
+    const float t0 = NSOF_MADD(B00, a0, B01 * a1);
+    const float t1 = NSOF_MADD(B10, a0, B11 * a1);
+    out[((size_t)blockIdx.z * hk + dy) * wk + dx] = NSOF_MADD(t0, b0, t1 * b1);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1321,12 +1335,12 @@ __global__ __launch_bounds__(256) void k_flow_upsample(const float* __restrict__
     const float2 p10 = S[(size_t)r1 * sw + sx], p11 = S[(size_t)r1 * sw + c1];
     float2 o;
     {
-        const float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-        o.x = (t0 * b0 + t1 * b1) * mul;
+        const float t0 = NSOF_MADD(p00.x, a0, p01.x * a1), t1 = NSOF_MADD(p10.x, a0, p11.x * a1);
+        o.x = NSOF_MADD(t0, b0, t1 * b1) * mul;
     }
     {
-        const float t0 = p00.y * a0 + p01.y * a1, t1 = p10.y * a0 + p11.y * a1;
-        o.y = (t0 * b0 + t1 * b1) * mul;
+        const float t0 = NSOF_MADD(p00.y, a0, p01.y * a1), t1 = NSOF_MADD(p10.y, a0, p11.y * a1);
+        o.y = NSOF_MADD(t0, b0, t1 * b1) * mul;
     }
     reinterpret_cast<float2*>(dst)[((size_t)blockIdx.z * dh + dy) * dw + dx] = o;
 }
@@ -1395,12 +1409,12 @@ __global__ __launch_bounds__(256) void k_flow_upsample2x2(const float* __restric
             const float2 p10 = ro ? (co ? v[2][1] : v[2][0]) : (co ? v[1][1] : v[1][0]);
             const float2 p11 = ro ? (co ? v[2][2] : v[2][1]) : (co ? v[1][2] : v[1][1]);
             {
-                const float t0 = p00.x * aa0 + p01.x * aa1, t1 = p10.x * aa0 + p11.x * aa1;
-                o[j].x = (t0 * bb0 + t1 * bb1) * mul;
+                const float t0 = NSOF_MADD(p00.x, aa0, p01.x * aa1), t1 = NSOF_MADD(p10.x, aa0, p11.x * aa1);
+                o[j].x = NSOF_MADD(t0, bb0, t1 * bb1) * mul;
             }
             {
-                const float t0 = p00.y * aa0 + p01.y * aa1, t1 = p10.y * aa0 + p11.y * aa1;
-                o[j].y = (t0 * bb0 + t1 * bb1) * mul;
+                const float t0 = NSOF_MADD(p00.y, aa0, p01.y * aa1), t1 = NSOF_MADD(p10.y, aa0, p11.y * aa1);
+                o[j].y = NSOF_MADD(t0, bb0, t1 * bb1) * mul;
             }
         }
         float2* drow = D + (size_t)(dy0 + i) * dw + dx0;
@@ -1459,8 +1473,8 @@ __global__ __launch_bounds__(256) void k_flow_upsample_walk(const float* __restr
 #pragma unroll
         for (int i = 0; i < NPL; i++) {
             const float2 p0 = pick(V, i0[i]), p1 = pick(V, i1[i]);
-            h[i].x = p0.x * a0[i] + p1.x * a1[i];
-            h[i].y = p0.y * a0[i] + p1.y * a1[i];
+            h[i].x = NSOF_MADD(p0.x, a0[i], p1.x * a1[i]);
+            h[i].y = NSOF_MADD(p0.y, a0[i], p1.y * a1[i]);
         }
     };
     float2 hA[NPL], hB[NPL];
@@ -1490,8 +1504,8 @@ __global__ __launch_bounds__(256) void k_flow_upsample_walk(const float* __restr
 #pragma unroll
             for (int i = 0; i < NPL; i++) {
                 const float2 t0 = hA[i], t1 = same ? hA[i] : hB[i];
-                o[i].x = (t0.x * b0 + t1.x * b1) * mul;
-                o[i].y = (t0.y * b0 + t1.y * b1) * mul;
+                o[i].x = NSOF_MADD(t0.x, b0, t1.x * b1) * mul;
+                o[i].y = NSOF_MADD(t0.y, b0, t1.y * b1) * mul;
             }
             float2* drow = D + (size_t)dy * dw + dx0;
             if (dx0 + 1 < dw && (dw & 1) == 0) {
@@ -1547,7 +1561,7 @@ void launch_polyexp_het_n(nsof_ctx* ctx, int n_img, const nsof_het_item* items, 
 // =========================================================================================
 // launchers
 // =========================================================================================
-int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
+int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
                      int H, int wk, int hk, const nsof_blur_taps& taps, float* out)
 {
     nsof_prof_scope ps(ctx, NSOF_K_PREP);
@@ -1653,6 +1667,7 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
     return NSOF_OK;
 }
 
+#ifndef NSOF_PYR_FMA
 int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R)
 {
     nsof_prof_scope ps(ctx, NSOF_K_POLYEXP);
@@ -1707,7 +1722,9 @@ int nsof_launch_blur_solve_exact(nsof_ctx* ctx, int n_pairs, const float* M, int
     return NSOF_OK;
 }
 
-int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw, int dh,
+#endif  // !NSOF_PYR_FMA
+
+int NSOF_PYR_NAME(nsof_launch_flow_upsample)(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw, int dh,
                               float mul)
 {
     nsof_prof_scope ps(ctx, NSOF_K_UPSAMPLE);
@@ -1737,7 +1754,7 @@ int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int 
 // =========================================================================================
 // work-list (shape-heterogeneous) launchers: one launch per stage and level over a device table
 // =========================================================================================
-int nsof_launch_prep_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
+int NSOF_PYR_NAME(nsof_launch_prep_het)(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
                          bool level0, const nsof_blur_taps& taps, float* I)
 {
     nsof_prof_scope ps(ctx, NSOF_K_PREP);
@@ -1799,6 +1816,7 @@ int nsof_launch_prep_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_item
     return NSOF_OK;
 }
 
+#ifndef NSOF_PYR_FMA
 int nsof_launch_polyexp_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
                             const nsof_poly_taps& taps, const float* I, float* R)
 {
@@ -1814,7 +1832,9 @@ int nsof_launch_polyexp_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
     return NSOF_OK;
 }
 
-int nsof_launch_flow_upsample_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+#endif  // !NSOF_PYR_FMA
+
+int NSOF_PYR_NAME(nsof_launch_flow_upsample_het)(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
                                   const float* src, float* dst, float mul)
 {
     nsof_prof_scope ps(ctx, NSOF_K_UPSAMPLE);

@@ -221,6 +221,7 @@ extern "C" int nsof_create(int device, nsof_ctx** out)
     ctx->stream = ctx->own_stream;
     if (const char* e = getenv("NSOF_POLYEXP_F32")) ctx->opt_polyexp_f32 = (e[0] && e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("NSOF_EXACT_ROWSUMS")) ctx->opt_exact_rowsums = (e[0] && e[0] != '0') ? 1 : 0;
+    if (const char* e = getenv("NSOF_PYR_FMA")) ctx->opt_pyr_fma = (e[0] && e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("NSOF_ROW_BANDS")) {
         const int v = atoi(e);
         ctx->opt_row_bands = v < 0 || v == 2 || v == 3 ? 0 : v;
@@ -268,9 +269,9 @@ extern "C" int nsof_set_stream(nsof_ctx* ctx, void* s)
 extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
 {
     if (!ctx) return NSOF_EINVAL;
-    if (option == NSOF_OPT_POLYEXP_F32 || option == NSOF_OPT_EXACT_ROWSUMS) {
+    if (option == NSOF_OPT_POLYEXP_F32 || option == NSOF_OPT_EXACT_ROWSUMS || option == NSOF_OPT_PYR_FMA) {
         if (value != 0 && value != 1) return nsof_set_error(ctx, NSOF_EINVAL, "option %d takes 0 or 1", option);
-        (option == NSOF_OPT_POLYEXP_F32 ? ctx->opt_polyexp_f32 : ctx->opt_exact_rowsums) = value;
+        (option == NSOF_OPT_POLYEXP_F32 ? ctx->opt_polyexp_f32 : option == NSOF_OPT_PYR_FMA ? ctx->opt_pyr_fma : ctx->opt_exact_rowsums) = value;
         return NSOF_OK;
     }
     if (option == NSOF_OPT_ROW_BANDS) {
@@ -295,6 +296,10 @@ extern "C" int nsof_get_option(const nsof_ctx* ctx, int option, int* value)
     }
     if (option == NSOF_OPT_ROW_BANDS) {
         *value = ctx->opt_row_bands;
+        return NSOF_OK;
+    }
+    if (option == NSOF_OPT_PYR_FMA) {
+        *value = ctx->opt_pyr_fma;
         return NSOF_OK;
     }
     return NSOF_EINVAL;
@@ -478,7 +483,7 @@ extern "C" int nsof_stage_pyr_level(nsof_ctx* ctx, int n_img, const uint8_t* d_s
     nsof_blur_taps taps;
     if ((rc = nsof_host_blur_taps(ks, sg, &taps)))
         return nsof_set_error(ctx, rc, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
-    return nsof_launch_prep(ctx, n_img, d_src, row_stride, img_stride, width, height, wk, hk, taps, d_out);
+    return NSOF_PYR_SEL(ctx, nsof_launch_prep, n_img, d_src, row_stride, img_stride, width, height, wk, hk, taps, d_out);
 }
 
 __global__ void k_recip_probe(long long n, const double* __restrict__ x, double* __restrict__ fast, double* __restrict__ ieee)
@@ -552,7 +557,7 @@ extern "C" int nsof_stage_flow_upsample(nsof_ctx* ctx, int n_pairs, const float*
                                         int dw, int dh, double pyr_scale)
 {
     if (!ctx || !d_src || !d_dst || n_pairs < 1 || sw < 1 || sh < 1 || dw < 1 || dh < 1) return NSOF_EINVAL;
-    return nsof_launch_flow_upsample(ctx, n_pairs, d_src, sw, sh, d_dst, dw, dh, (float)(1. / pyr_scale));
+    return NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample, n_pairs, d_src, sw, sh, d_dst, dw, dh, (float)(1. / pyr_scale));
 }
 
 // ---- the Farneback driver --------------------------------------------------------------------
@@ -708,9 +713,9 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
             if (int r = nsof_host_blur_taps(ks, sg, &bt))
                 return nsof_set_error(ctx, r, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
             const size_t nk = (size_t)wk * hk;
-            if (sequence) return nsof_launch_prep(ctx, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, bt, I);
+            if (sequence) return NSOF_PYR_SEL(ctx, nsof_launch_prep, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, bt, I);
             for (int i = 0; i < 2; i++)
-                if (int r = nsof_launch_prep(ctx, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width, height, wk,
+                if (int r = NSOF_PYR_SEL(ctx, nsof_launch_prep, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width, height, wk,
                                              hk, bt, I + (size_t)i * B * nk))
                     return r;
             return NSOF_OK;
@@ -744,7 +749,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
                 NSOF_HIP(ctx, hipEventRecord(EV(k, 2), mainS));
                 NSOF_HIP(ctx, hipStreamWaitEvent(sideS, EV(k, 2), 0));
                 StreamSwap sw(ctx, sideS);
-                if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, fb[cur], wk, hk, fb[cur ^ 1], w1, h1, (float)(1. / pyr_scale))))
+                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample, n_pairs, fb[cur], wk, hk, fb[cur ^ 1], w1, h1, (float)(1. / pyr_scale))))
                     return rc;
                 cur ^= 1;
                 NSOF_HIP(ctx, hipEventRecord(EV(k - 1, 3), sideS));
@@ -772,7 +777,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         } else if (fold_ups) {
             pending_ups = true;   // fb[cur] still holds the coarse flow (pw x ph)
         } else {
-            if ((rc = nsof_launch_flow_upsample(ctx, n_pairs, fb[cur], pw, ph, fb[cur ^ 1], wk, hk,
+            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample, n_pairs, fb[cur], pw, ph, fb[cur ^ 1], wk, hk,
                                                 (float)(1. / pyr_scale))))
                 return rc;
             cur ^= 1;
@@ -780,11 +785,11 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         // image-major: dI [n_img][hk][wk], dR [n_img][5*hk*wk].  Pairs: all prev frames then all next frames
         // (R1 = R0 + B images); sequence: the frames in order (R1 = R0 + 1 image).
         if (sequence) {
-            if ((rc = nsof_launch_prep(ctx, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, btaps, dI)))
+            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, btaps, dI)))
                 return rc;
         } else {
             for (int i = 0; i < 2; i++)
-                if ((rc = nsof_launch_prep(ctx, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width,
+                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width,
                                            height, wk, hk, btaps, dI + (size_t)i * B * nk)))
                     return rc;
         }

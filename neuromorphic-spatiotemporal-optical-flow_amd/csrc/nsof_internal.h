@@ -27,6 +27,7 @@ struct nsof_ctx {
     int opt_polyexp_f32 = 0;   // NSOF_OPT_POLYEXP_F32
     int opt_exact_rowsums = 1; // NSOF_OPT_EXACT_ROWSUMS (default: the library's row-sum order)
     int opt_row_bands = 0;     // NSOF_OPT_ROW_BANDS: 0 off, 1 automatic, >= 4 rows per band
+    int opt_pyr_fma = 0;       // NSOF_OPT_PYR_FMA: pyramid blur / resamples with fused multiply-adds (arithmetic variant twin)
     char err[512] = {0};
     // reusable device workspace of the Farneback driver
     void* ws = nullptr;
@@ -150,6 +151,16 @@ int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
                             const float* flow_in, float* flow_out, bool final, int winsize);
 int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
                      int H, int wk, int hk, const nsof_blur_taps& taps, float* out);
+// The *_fma twins (farneback_kernels.hip compiled with -DNSOF_PYR_FMA): same taps and order, every tap / blend one fused
+// multiply-add -- selected by ctx->opt_pyr_fma through the *_sel wrappers below.
+int nsof_launch_prep_fma(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
+                         int H, int wk, int hk, const nsof_blur_taps& taps, float* out);
+int nsof_launch_prep_het_fma(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
+                             bool level0, const nsof_blur_taps& taps, float* I);
+int nsof_launch_flow_upsample_fma(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw,
+                                  int dh, float mul);
+int nsof_launch_flow_upsample_het_fma(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
+                                      const float* src, float* dst, float mul);
 int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps,
                         float* R);
 // R0/R1: planar [5][h][w] expansion of prev/next of pair 0; pair z is at +z*pair_stride floats.
@@ -161,6 +172,7 @@ int nsof_launch_blur_solve_exact(nsof_ctx* ctx, int n_pairs, const float* M, int
                                  float* flow);
 int nsof_launch_flow_upsample(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw,
                               int dh, float mul);
+#define NSOF_PYR_SEL(ctx, fn, ...) ((ctx)->opt_pyr_fma ? fn##_fma(ctx, __VA_ARGS__) : fn(ctx, __VA_ARGS__))
 bool nsof_iterate_supported(int winsize, int W, int H);
 // Fused iteration; flow_in != flow_out.
 int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,

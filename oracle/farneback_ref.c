@@ -109,6 +109,18 @@ int nsof_ref_gaussian_kernel(int n, double sigma, float* out)
     return NSOF_REF_OK;
 }
 
+/* ---- arithmetic variant of the pyramid stages ----------------------------------------------
+ * The float Gaussian blur and the bilinear resamples below exist in two variants.  Variant 0 (default) rounds every
+ * product and every sum, as the library's generic C++ loops do when they are compiled without contraction.  Variant 1
+ * evaluates the same taps in the same order with ONE fused multiply-add per tap / blend (the leading product still
+ * rounded): how an AVX2+FMA3 build of the library's vector loops (v_muladd in its separable-filter and resize kernels)
+ * contracts them.  Which one a given cv2 wheel executes cannot be pinned in this image; DESIGN.md section 2 states how
+ * far the flow moves between the two.  nsof_ref_set_pyr_fma selects the variant for subsequent calls (process-wide). */
+static int g_pyr_fma = 0;
+void nsof_ref_set_pyr_fma(int on) { g_pyr_fma = on ? 1 : 0; }
+int nsof_ref_get_pyr_fma(void) { return g_pyr_fma; }
+static inline float madd(float a, float b, float c) { return g_pyr_fma ? fmaf(a, b, c) : a * b + c; }
+
 /* ---- GaussianBlur on CV_32FC1 via sepFilter2D, BORDER_REFLECT_101 -------------------
  * Row pass first (float accumulation), then column pass (float accumulation).
  *   row, ksize <= 5 (SymmRowSmallFilter):  S0*k0 + (S-1 + S1)*k1 [+ (S-2 + S2)*k2]
@@ -139,12 +151,12 @@ static int gaussian_blur_f32(const float* src, int w, int h, float* dst, int ksi
             const int* ix = xi + x + r; /* ix[j] = reflected x+j */
             float s;
             if (ksize == 3) {
-                s = S[ix[0]] * kc[0] + (S[ix[-1]] + S[ix[1]]) * kc[1];
+                s = madd(S[ix[-1]] + S[ix[1]], kc[1], S[ix[0]] * kc[0]);
             } else if (ksize == 5) {
-                s = S[ix[0]] * kc[0] + (S[ix[-1]] + S[ix[1]]) * kc[1] + (S[ix[-2]] + S[ix[2]]) * kc[2];
+                s = madd(S[ix[-2]] + S[ix[2]], kc[2], madd(S[ix[-1]] + S[ix[1]], kc[1], S[ix[0]] * kc[0]));
             } else {
                 s = kbuf[0] * S[ix[-r]];
-                for (int k = 1; k < ksize; k++) s += kbuf[k] * S[ix[k - r]];
+                for (int k = 1; k < ksize; k++) s = madd(kbuf[k], S[ix[k - r]], s);
             }
             D[x] = s;
         }
@@ -155,13 +167,13 @@ static int gaussian_blur_f32(const float* src, int w, int h, float* dst, int ksi
         if (ksize == 3) {
             const float* Sm = tmp + (size_t)reflect101(y - 1, h) * w;
             const float* Sp = tmp + (size_t)reflect101(y + 1, h) * w;
-            for (int x = 0; x < w; x++) D[x] = (Sm[x] + Sp[x]) * kc[1] + S0[x] * kc[0];
+            for (int x = 0; x < w; x++) D[x] = madd(Sm[x] + Sp[x], kc[1], S0[x] * kc[0]);
         } else {
             for (int x = 0; x < w; x++) D[x] = kc[0] * S0[x];
             for (int k = 1; k <= r; k++) {
                 const float* Sp = tmp + (size_t)reflect101(y + k, h) * w;
                 const float* Sm = tmp + (size_t)reflect101(y - k, h) * w;
-                for (int x = 0; x < w; x++) D[x] += kc[k] * (Sp[x] + Sm[x]);
+                for (int x = 0; x < w; x++) D[x] = madd(kc[k], Sp[x] + Sm[x], D[x]);
             }
         }
     }
@@ -204,7 +216,7 @@ int nsof_ref_resize_linear(const float* src, int sw, int sh, int cn, float* dst,
             int sx = xofs[dx];
             float a1 = xa[dx], a0 = 1.f - a1;
             for (int c = 0; c < cn; c++) {
-                if (sx + 1 < sw) D[dx * cn + c] = S[sx * cn + c] * a0 + S[(sx + 1) * cn + c] * a1;
+                if (sx + 1 < sw) D[dx * cn + c] = madd(S[sx * cn + c], a0, S[(sx + 1) * cn + c] * a1);
                 else D[dx * cn + c] = S[sx * cn + c] * 1.f; /* dx >= xmax branch */
             }
         }
@@ -217,7 +229,7 @@ int nsof_ref_resize_linear(const float* src, int sw, int sh, int cn, float* dst,
         const float* S0 = hbuf + (size_t)clampi(sy, 0, sh - 1) * dw * cn;
         const float* S1 = hbuf + (size_t)clampi(sy + 1, 0, sh - 1) * dw * cn;
         float* D = dst + (size_t)dy * dw * cn;
-        for (int i = 0; i < dw * cn; i++) D[i] = S0[i] * b0 + S1[i] * b1;
+        for (int i = 0; i < dw * cn; i++) D[i] = madd(S0[i], b0, S1[i] * b1);
     }
     free(xofs); free(xa); free(hbuf);
     return NSOF_REF_OK;

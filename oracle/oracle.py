@@ -17,7 +17,8 @@ _lib = None
 
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
-    if force or not os.path.exists(_SO):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return _SO
 
@@ -155,8 +156,9 @@ def perf_lib():
         import hashlib
         tag = hashlib.sha1(host_cpu()[0].encode()).hexdigest()[:10]
         so = os.path.join(_HERE, "_build", f"libnsof_oracle_perf_{tag}.so")
-        if not os.path.exists(so):
-            subprocess.check_call(["make", "-s", "-C", _HERE, "perf", f"PERF_OUT=_build/libnsof_oracle_perf_{tag}.so"])
+        srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
+            subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "perf", f"PERF_OUT=_build/libnsof_oracle_perf_{tag}.so"])
         l = C.CDLL(so)
         l.nsof_ref_farneback_u8_many.restype = C.c_int
         l.nsof_ref_farneback_u8_many.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_int,
@@ -164,6 +166,9 @@ def perf_lib():
                                                  C.c_double, C.c_int, C.c_int]
         l.nsof_ref_has_openmp.restype = C.c_int
         _perf = l
+        l.nsof_ref_set_pyr_fma.argtypes = [C.c_int]
+        l.nsof_ref_set_pyr_fma.restype = None
+        l.nsof_ref_set_pyr_fma(1 if _pyr_fma else 0)
     return _perf
 
 
@@ -191,6 +196,21 @@ def accum_slices_per_s(x, y, t, H, W, slice_us=1000, active_v=-6.0, silent_v=0.0
     dt = time.perf_counter() - t0
     l.nsof_ref_set_threads(1)
     return n_slices / dt, w
+
+
+def set_pyr_fma(on):
+    """Arithmetic variant of the pyramid stages for subsequent calls (see farneback_ref.c): False = every product and sum
+    rounded (default), True = one fused multiply-add per tap / blend.  Applies to the checker and the perf build."""
+    global _pyr_fma
+    _pyr_fma = bool(on)
+    for l in (lib(), _perf):
+        if l is not None:
+            l.nsof_ref_set_pyr_fma.argtypes = [C.c_int]
+            l.nsof_ref_set_pyr_fma.restype = None
+            l.nsof_ref_set_pyr_fma(1 if on else 0)
+
+
+_pyr_fma = False
 
 
 def farneback_many(prevs, nexts, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags=0, n_threads=1):

@@ -562,3 +562,55 @@ def test_more_pairs_than_one_grid_holds(nsof_lib, ctx, torch_dev):
     for i in (0, 1, 32766, 32767, 32768, n - 1):
         one = nsof_lib.calcOpticalFlowFarneback(host[i], host[i + 1], None, *P.as_kwargs().values(), ctx=ctx)
         assert np.array_equal(flow[i].cpu().numpy(), one), i
+
+
+@pytest.mark.gpu
+def test_pyramid_fma_variant_twin(nsof_lib, ctx, oracle, torch_dev):
+    """NSOF_OPT_PYR_FMA: the arithmetic-variant twin of the pyramid stages (float Gaussian blur + bilinear resamples with
+    one fused multiply-add per tap / blend, as an AVX2+FMA3 build of the library's vector loops contracts them).  GPU and
+    CPU oracle agree bit for bit IN EACH VARIANT -- pyramid levels of every kernel family (same-size, exact decimation,
+    generic scales), the flow resample, and the whole call for the reference's three parameter sets -- and the two
+    variants differ from each other (by what DESIGN.md section 2 reports)."""
+    import torch
+    from nsof import _lib, synth
+    assert ctx.get_option(_lib.OPT_PYR_FMA) == 0
+    shapes = [(270, 480), (200, 303), (256, 512)]
+    try:
+        res = {}
+        for fma in (0, 1):
+            ctx.set_option(_lib.OPT_PYR_FMA, fma)
+            oracle.set_pyr_fma(bool(fma))
+            for shape in shapes:
+                prev, nxt = synth.make_pair(100 + shape[0], *shape)
+                d = _dev(torch_dev, np.stack([prev, nxt]))
+                for pyr_scale, level in [(0.5, 0), (0.5, 1), (0.5, 2), (0.5, 3), (0.6, 1), (0.6, 2), (0.6, 3), (0.75, 2)]:
+                    wk, hk, _, _ = nsof_lib.level_size(shape[1], shape[0], pyr_scale, level)
+                    out = torch.empty((2, hk, wk), dtype=torch.float32, device=torch_dev)
+                    ctx.check(ctx._lib.nsof_stage_pyr_level(ctx.ptr, 2, d.data_ptr(), shape[1], shape[0] * shape[1], shape[1],
+                                                            shape[0], pyr_scale, level, out.data_ptr()))
+                    ctx.synchronize()
+                    got = out.cpu().numpy()
+                    for i, img in enumerate((prev, nxt)):
+                        want = oracle.pyr_level(img, pyr_scale, level)
+                        assert np.array_equal(got[i], want), (fma, shape, pyr_scale, level, float(np.abs(got[i] - want).max()))
+            rng = np.random.default_rng(5)
+            for (sh, sw), (dh, dw), ps in [((68, 120), (135, 240), 0.5), ((58, 79), (97, 131), 0.6), ((135, 400), (270, 800), 0.5)]:
+                src = (rng.standard_normal((2, sh, sw, 2)) * 3).astype(np.float32)
+                dsrc = _dev(torch_dev, src)
+                out = torch.empty((2, dh, dw, 2), dtype=torch.float32, device=torch_dev)
+                ctx.check(ctx._lib.nsof_stage_flow_upsample(ctx.ptr, 2, dsrc.data_ptr(), sw, sh, out.data_ptr(), dw, dh, ps))
+                ctx.synchronize()
+                want = oracle.resize_linear(src[0], dw, dh) * np.float32(1. / ps)
+                assert np.array_equal(out.cpu().numpy()[0], want), (fma, sh, sw)
+            for name, P in (("A", A), ("B", B), ("C", Cc)):
+                prev, nxt = synth.make_pair(77, 270, 480)
+                got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *P, ctx=ctx)
+                want = oracle.farneback(prev, nxt, *P)
+                assert np.array_equal(got, want), (fma, name, float(np.abs(got - want).max()))
+                res[(fma, name)] = got
+    finally:
+        ctx.set_option(_lib.OPT_PYR_FMA, 0)
+        oracle.set_pyr_fma(False)
+    for name in "ABC":
+        d = float(np.abs(res[(0, name)] - res[(1, name)]).max())
+        assert 0 < d < 5e-3, (name, d)
