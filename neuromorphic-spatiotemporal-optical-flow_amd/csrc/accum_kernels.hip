@@ -150,10 +150,23 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, f
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
-__device__ __forceinline__ void mark(unsigned* mask, unsigned* list, unsigned* count, unsigned pix, unsigned bit)
+// Marks (pixel, slice bit); a pixel's first touch in this group enters the compact list once.  The list's counter is ONE
+// word: appended to per lane it serialises every first touch of a group at the L2 atomic unit (~10 ns each: 300 us for the
+// 33 k events of a 32-slice group at 1 M events/s, found with rocprofv3 in round 3), so the appends of a wave are
+// aggregated -- one atomicAdd of the wave's count, ranks from the ballot.  Call with the whole wave (inactive lanes pass
+// active = false); list == nullptr (dense update: no list is read) skips the list entirely.
+__device__ __forceinline__ void mark(unsigned* mask, unsigned* list, unsigned* count, unsigned pix, unsigned bit, bool active)
 {
-    const unsigned old = atomicOr(&mask[pix], bit);
-    if (old == 0) list[atomicAdd(count, 1u)] = pix;  // first touch in this group: enters the compact list once
+    const unsigned old = active ? atomicOr(&mask[pix], bit) : 1u;
+    if (!list) return;
+    const bool first = active && old == 0;
+    const unsigned long long b = __ballot(first);
+    if (!b) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(b));
+    base = __shfl(base, leader);
+    if (first) list[base + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = pix;
 }
 
 // Scheme 1 (:208-217): every event of the group marks (pixel, its slice).  bounds = event
@@ -163,14 +176,14 @@ __global__ __launch_bounds__(256) void k_scatter_v1(const short* __restrict__ x,
                                                      int n_sl, int W, unsigned* mask, unsigned* list, unsigned* count)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_ev) return;
-    const long long e = ev0 + i;
+    const bool live = i < n_ev;
+    const long long e = ev0 + (live ? i : 0);
     int lo = 0, hi = n_sl;  // largest s with bounds[s] <= e
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (bounds[mid] <= e) lo = mid; else hi = mid;
     }
-    mark(mask, list, count, (unsigned)y[e] * (unsigned)W + (unsigned)x[e], 1u << lo);
+    mark(mask, list, count, (unsigned)y[e] * (unsigned)W + (unsigned)x[e], 1u << lo, live);
 }
 
 // Scheme 2 (:237-269), one slice: eligible <=> next_ok[pix] <= t_first; eligible pixels are
@@ -184,15 +197,19 @@ __global__ __launch_bounds__(256) void k_scatter_v2(const short* __restrict__ x,
                                                      unsigned* count)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_ev) return;
-    const long long e = ev0 + i;
-    if (pol_sel >= 0 && (int)p[e] != pol_sel) return;
+    bool live = i < n_ev;
+    const long long e = ev0 + (live ? i : 0);
+    if (live && pol_sel >= 0 && (int)p[e] != pol_sel) live = false;
     const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
-    const long long ok = __hip_atomic_load(&next_ok[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ok <= t_first) {
-        __hip_atomic_store(&next_ok[pix], t_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        mark(mask, list, count, pix, bit);
+    bool hit = false;
+    if (live) {
+        const long long ok = __hip_atomic_load(&next_ok[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ok <= t_first) {
+            __hip_atomic_store(&next_ok[pix], t_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hit = true;
+        }
     }
+    mark(mask, list, count, pix, bit, hit);
 }
 
 // Fused state update over the touched pixels only (silent_v inside the dead zone).
@@ -258,6 +275,134 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
     }
 }
 
+// ---- scheme 2 without a launch per slice (round 3) ----------------------------------------------------------------------
+// The refractory rule (event_mem_sim.py:237-269) looks like a chain over slices -- slice s+1 tests the next_ok that slice s
+// wrote -- but the chain is PER PIXEL: a pixel's next_ok depends on that pixel's own earlier events only, and within a slice
+// every event of a pixel sees the same next_ok (NumPy reads next_ok[ys, xs] before it writes).  So a group of up to 32
+// slices needs ONE scatter, "which slices have an event (of the array's polarity) at this pixel" (bit s of E), and the
+// eligibility walk moves into the fused state update: per touched pixel, over the set bits of E in slice order,
+//     if next_ok <= t_first[s]:  the pixel is driven in slice s;  next_ok = t_last[s] + REFRACTORY
+// with the per-slice constants in a 64-entry table.  No atomics on next_ok, two launches per group and array as in scheme 1.
+struct RefrTab {
+    long long t_first[32], t_next[32];
+};
+
+// E bits of a group: split == 0: every event -> array 0 (magnitude mode); split == 1: p == 1 -> array 0, p == 0 -> array 1
+// (:238, :250; other polarity values drive nothing).  bounds as in k_scatter_v1.
+__global__ __launch_bounds__(256) void k_scatter_v2g(const short* __restrict__ x, const short* __restrict__ y,
+                                                      const signed char* __restrict__ p, long long ev0, long long n_ev,
+                                                      const long long* __restrict__ bounds, int n_sl, int W, int split,
+                                                      unsigned* mask0, unsigned* list0, unsigned* count0, unsigned* mask1,
+                                                      unsigned* list1, unsigned* count1)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n_ev;
+    const long long e = ev0 + (live ? i : 0);
+    int arr = 0;
+    if (split) {
+        const int pv = (int)p[e];
+        arr = pv == 1 ? 0 : (pv == 0 ? 1 : -1);
+    }
+    int lo = 0, hi = n_sl;  // largest s with bounds[s] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bounds[mid] <= e) lo = mid; else hi = mid;
+    }
+    const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
+    mark(mask0, list0, count0, pix, 1u << lo, live && arr == 0);
+    if (split) mark(mask1, list1, count1, pix, 1u << lo, live && arr == 1);
+}
+
+// slices with an event -> slices in which the pixel is driven; ok = the pixel's next_ok (updated)
+__device__ __forceinline__ unsigned refractory_walk(unsigned e, long long& ok, const long long* tf, const long long* tn)
+{
+    unsigned m = 0;
+    for (; e; e &= e - 1) {
+        const int s = __ffs((int)e) - 1;
+        if (ok <= tf[s]) {
+            m |= 1u << s;
+            ok = tn[s];
+        }
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_update_sparse_v2(float* __restrict__ w, unsigned* __restrict__ mask,
+                                                           long long* __restrict__ next_ok, const unsigned* __restrict__ list,
+                                                           const unsigned* __restrict__ count, RefrTab tab, float v_act)
+{
+    __shared__ long long tf[32], tn[32];
+    if (threadIdx.x < 32) { tf[threadIdx.x] = tab.t_first[threadIdx.x]; tn[threadIdx.x] = tab.t_next[threadIdx.x]; }
+    __syncthreads();
+    const unsigned n = *count;
+    const Drive da = drive_of(v_act);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned pix = list[i];
+        const unsigned e = mask[pix];
+        mask[pix] = 0;
+        long long ok = next_ok[pix];
+        unsigned m = refractory_walk(e, ok, tf, tn);
+        if (m) {
+            next_ok[pix] = ok;
+            float ww = w[pix];
+            for (; m; m &= m - 1) ww = update_drive(ww, da);
+            w[pix] = ww;
+        }
+    }
+}
+
+template <bool SIL_NOOP>
+__global__ __launch_bounds__(256) void k_update_dense_v2(float* __restrict__ w, unsigned* __restrict__ mask,
+                                                          long long* __restrict__ next_ok, size_t n4, size_t n, int n_sl,
+                                                          RefrTab tab, float v_act, float v_sil)
+{
+    __shared__ long long tf[32], tn[32];
+    if (threadIdx.x < 32) { tf[threadIdx.x] = tab.t_first[threadIdx.x]; tn[threadIdx.x] = tab.t_next[threadIdx.x]; }
+    __syncthreads();
+    const Drive da = drive_of(v_act), ds = drive_of(v_sil);
+    auto one = [&](float ww, unsigned e, size_t pix) {
+        unsigned m = 0;
+        if (e) {
+            long long ok = next_ok[pix];
+            m = refractory_walk(e, ok, tf, tn);
+            if (m) next_ok[pix] = ok;
+        }
+        if (SIL_NOOP) {
+            for (; m; m &= m - 1) ww = update_drive(ww, da);
+        } else {
+            for (int s = 0; s < n_sl; s++) {
+                const bool act = (m >> s) & 1u;
+                Drive d;
+                d.ka = act ? da.ka : ds.ka;
+                d.s = act ? da.s : ds.s;
+                d.b = act ? da.b : ds.b;
+                ww = update_drive(ww, d);
+            }
+        }
+        return ww;
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        if (4 * i + 3 < n) {
+            float4 ww = reinterpret_cast<float4*>(w)[i];
+            const uint4 mm = reinterpret_cast<uint4*>(mask)[i];
+            const bool any = (mm.x | mm.y | mm.z | mm.w) != 0;
+            if (SIL_NOOP && !any) continue;                       // nothing driven: w unchanged bit for bit
+            if (any) reinterpret_cast<uint4*>(mask)[i] = make_uint4(0, 0, 0, 0);
+            ww.x = one(ww.x, mm.x, 4 * i);
+            ww.y = one(ww.y, mm.y, 4 * i + 1);
+            ww.z = one(ww.z, mm.z, 4 * i + 2);
+            ww.w = one(ww.w, mm.w, 4 * i + 3);
+            reinterpret_cast<float4*>(w)[i] = ww;
+        } else {
+            for (size_t j = 4 * i; j < n; j++) {
+                const unsigned e = mask[j];
+                mask[j] = 0;
+                w[j] = one(w[j], e, j);
+            }
+        }
+    }
+}
+
 // ---- scheme 2 as ONE graph launch per group of slices ---------------------------------------------------------------
 // The refractory rule makes every slice's scatter depend on the previous slice's, so a group of 32 slices is 32 (split
 // mode: 64) tiny dependent launches + the fused update -- launch overhead, not work, bounds scheme 2.  Here the same
@@ -283,15 +428,21 @@ __global__ __launch_bounds__(256) void k_scatter_v2_tab(const short* __restrict_
     if (s >= gr.g) return;
     const SliceRec sl = slices[gr.first + s];
     const unsigned bit = 1u << s;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < sl.n; i += (long long)gridDim.x * 256) {
-        const long long e = sl.lo + i;
-        if (pol_sel >= 0 && (int)p[e] != pol_sel) continue;
+    for (long long i0 = (long long)blockIdx.x * 256; i0 < sl.n; i0 += (long long)gridDim.x * 256) {   // whole waves walk together
+        const long long i = i0 + threadIdx.x;
+        bool live = i < sl.n;
+        const long long e = sl.lo + (live ? i : 0);
+        if (live && pol_sel >= 0 && (int)p[e] != pol_sel) live = false;
         const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
-        const long long ok = __hip_atomic_load(&next_ok[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ok <= sl.t_first) {
-            __hip_atomic_store(&next_ok[pix], sl.t_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            mark(mask, list, count, pix, bit);
+        bool hit = false;
+        if (live) {
+            const long long ok = __hip_atomic_load(&next_ok[pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ok <= sl.t_first) {
+                __hip_atomic_store(&next_ok[pix], sl.t_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hit = true;
+            }
         }
+        mark(mask, list, count, pix, bit, hit);
     }
 }
 
@@ -448,6 +599,7 @@ struct nsof_accum {
     hipGraphExec_t graph = nullptr;
     bool graph_dense = false, graph_sparse_ok = false;
     int use_graph = -1;   // -1: from the environment (NSOF_ACCUM_GRAPH=1 switches it on), 0 / 1: forced
+    int v2_per_slice = -1;   // scheme 2: 0 = one scatter per group + refractory walk in the update (default), 1 = one scatter per slice
 };
 
 static int accum_alloc(nsof_ctx* ctx, void** p, size_t bytes)
@@ -655,6 +807,11 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         const char* e = getenv("NSOF_ACCUM_GRAPH");
         a->use_graph = (e && e[0] == '1') ? 1 : 0;
     }
+    if (a->v2_per_slice < 0) {   // NSOF_ACCUM_V2=slices: round 2's one-scatter-launch-per-slice form (A/B runs)
+        const char* e = getenv("NSOF_ACCUM_V2");
+        a->v2_per_slice = (e && e[0] == 's') ? 1 : 0;
+    }
+    if (a->use_graph) a->v2_per_slice = 1;   // the graph replays the per-slice chain
     if (a->scheme == 2 && a->use_graph && n_slices > 0) {
         // groups of this call (same rule as below: up to 32 slices, ending right after a snapshot slice)
         std::vector<GroupRec> groups;
@@ -743,11 +900,17 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         }
         const long long ge0 = rel[s0], ge1 = rel[s0 + g], gn = ge1 - ge0;
         NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 2 * sizeof(unsigned), ctx->stream));
+        unsigned* const l0 = sparse ? a->list[0] : nullptr;                      // the dense update reads no list
+        unsigned* const l1 = sparse ? a->list[a->split ? 1 : 0] : nullptr;
         if (gn > 0) {
             nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
             if (a->scheme == 1) {
                 hipLaunchKernelGGL(k_scatter_v1, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx,
-                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], a->list[0], a->count);
+                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], l0, a->count);
+            } else if (!a->v2_per_slice) {
+                hipLaunchKernelGGL(k_scatter_v2g, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx, a->dy,
+                                   a->dp, ge0, gn, a->dbounds + s0, (int)g, a->W, a->split ? 1 : 0, a->mask[0], l0,
+                                   a->count, a->mask[a->split ? 1 : 0], l1, a->count + 1);
             } else {
                 for (int64_t s = 0; s < g; s++) {
                     const long long lo = rel[s0 + s], hi = rel[s0 + s + 1];
@@ -758,14 +921,14 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
                     if (a->split) {
                         hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
                                            hi - lo, 1, t_first, t_next, a->W, bit, a->next_ok[0], a->mask[0],
-                                           a->list[0], a->count);
+                                           l0, a->count);
                         hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
                                            hi - lo, 0, t_first, t_next, a->W, bit, a->next_ok[1], a->mask[1],
-                                           a->list[1], a->count + 1);
+                                           l1, a->count + 1);
                     } else {
                         hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
                                            hi - lo, -1, t_first, t_next, a->W, bit, a->next_ok[0], a->mask[0],
-                                           a->list[0], a->count);
+                                           l0, a->count);
                     }
                 }
             }
@@ -773,8 +936,29 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         }
         {
             nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+            RefrTab tab;
+            const bool refr = a->scheme == 2 && !a->v2_per_slice;
+            if (refr)
+                for (int s = 0; s < 32; s++) {
+                    const bool live = s < g && rel[s0 + s + 1] > rel[s0 + s];
+                    tab.t_first[s] = live ? a->h_tfirst[s0 + s] : 0;
+                    tab.t_next[s] = live ? a->h_tnext[s0 + s] : 0;
+                }
             for (int i = 0; i < narr; i++) {
-                if (sparse) {
+                if (refr) {
+                    const size_t n4 = (a->npx + 3) / 4;
+                    if (sparse) {
+                        if (gn > 0)
+                            hipLaunchKernelGGL(k_update_sparse_v2, dim3(grid_for((size_t)gn, 1024)), dim3(256), 0, ctx->stream,
+                                               a->w[i], a->mask[i], a->next_ok[i], a->list[i], a->count + i, tab, v_act);
+                    } else if (dead_zone) {
+                        hipLaunchKernelGGL(k_update_dense_v2<true>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream, a->w[i],
+                                           a->mask[i], a->next_ok[i], n4, a->npx, (int)g, tab, v_act, a->silent_v);
+                    } else {
+                        hipLaunchKernelGGL(k_update_dense_v2<false>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream, a->w[i],
+                                           a->mask[i], a->next_ok[i], n4, a->npx, (int)g, tab, v_act, a->silent_v);
+                    }
+                } else if (sparse) {
                     if (gn > 0)
                         hipLaunchKernelGGL(k_update_sparse, dim3(grid_for((size_t)gn, 1024)), dim3(256), 0, ctx->stream,
                                            a->w[i], a->mask[i], a->list[i], a->count + i, (int)g, v_act);

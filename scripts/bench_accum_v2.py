@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Scheme 2 (DC bias + event overlay, refractory rule) of the accumulator on the 3840x2160 / 1 M events/s stream:
-slices/s in split and magnitude mode, with the per-slice scatters as separate launches (NSOF_ACCUM_GRAPH=0) and as
-one HIP graph launch per group of 32 slices (NSOF_ACCUM_GRAPH=1).  One JSON line."""
+slices/s in split and magnitude mode, sparse (touched pixels only) and dense (every pixel, the roofline run): the default
+form (ONE scatter per group of 32 slices, the per-pixel refractory walk inside the fused state update), round 2's form with
+one scatter launch per slice (NSOF_ACCUM_V2=slices) and that chain as one HIP graph launch per group (NSOF_ACCUM_GRAPH=1).
+One JSON line."""
 import json
 import os
 import subprocess
@@ -22,8 +24,8 @@ def measure():
     n = len(idx) - 1
     out = {}
     ctx = nsof.Context(0)
-    for pol in ("split", "magnitude"):
-        acc = Accumulator(2160, 3840, 2, pol, -6.0, 0.0, ctx=ctx)
+    for pol, dense in (("split", False), ("magnitude", False), ("split", True), ("magnitude", True)):
+        acc = Accumulator(2160, 3840, 2, pol, -6.0, 0.0, ctx=ctx, dense=dense)
         acc.set_events(x, y, p, t, idx)
         acc.run(0, n)
         ctx.synchronize()
@@ -36,7 +38,7 @@ def measure():
             ctx.synchronize()
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
-        out[pol] = {"slices_per_s": round(n / best, 1), "wall_ms": round(best * 1e3, 2),
+        out[pol + ("_dense" if dense else "")] = {"slices_per_s": round(n / best, 1), "wall_ms": round(best * 1e3, 2),
                     "w_checksum": float(np.asarray(acc.w(), np.float64).sum())}
         acc.close()
     return out
@@ -47,12 +49,13 @@ def main():
         print(json.dumps(measure()))
         return
     res = {}
-    for name, g in (("launch_per_slice", "0"), ("graph_per_group", "1")):
+    for name, env in (("scatter_per_group", {}), ("launch_per_slice", {"NSOF_ACCUM_V2": "slices"}),
+                      ("graph_per_group", {"NSOF_ACCUM_GRAPH": "1"})):
         r = subprocess.run([sys.executable, __file__, "--child"], capture_output=True, text=True,
-                           env=dict(os.environ, NSOF_ACCUM_GRAPH=g, NSOF_SKIP_BUILD="1"), timeout=600)
+                           env=dict(os.environ, NSOF_SKIP_BUILD="1", **env), timeout=600)
         res[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    res["same_state"] = all(res["launch_per_slice"][k]["w_checksum"] == res["graph_per_group"][k]["w_checksum"]
-                            for k in ("split", "magnitude"))
+    res["same_state"] = all(res["scatter_per_group"][k]["w_checksum"] == res[o][k]["w_checksum"]
+                            for k in res["scatter_per_group"] for o in ("launch_per_slice", "graph_per_group"))
     print(json.dumps(res))
 
 
