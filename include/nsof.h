@@ -139,7 +139,9 @@ typedef struct nsof_pair_desc {
  * field is in host memory).  All pairs share every kernel launch (a work list per pyramid level), so many small ROI
  * calls cost about as much as one; the list is processed in chunks whose upload, compute and download overlap on
  * three streams.  Buffers from nsof_host_alloc() (page-locked) are copied to/from directly, other memory goes
- * through an internal pinned staging buffer.  Result per pair == nsof_farneback_u8 of that pair, bit for bit. */
+ * through an internal pinned staging buffer.  Result per pair == nsof_farneback_u8 of that pair, bit for bit, in the default
+ * mode; with the opt-in modes that depend on the batch (NSOF_OPT_ROW_BANDS in automatic mode picks its band height from the
+ * batch size; a uniform list takes the uniform driver, where NSOF_OPT_POLYEXP_F32 applies) only to their tolerance. */
 int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs,
                             double pyr_scale, int levels, int winsize, int iterations,
                             int poly_n, double poly_sigma, int flags);

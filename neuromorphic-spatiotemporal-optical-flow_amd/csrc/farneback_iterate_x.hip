@@ -205,6 +205,9 @@ __device__ __forceinline__ void x_producer_loop(const XRing& ring, const Planes&
         x_produce<MH>(in[TS][0], fl[TS][0], ring, R0, R1, F, W, H, xc, col, 4 * t + MH + 2 * GP);
         x_produce<MH>(in[TS][1], fl[TS][1], ring, R0, R1, F, W, H, xc, col, 4 * t + MH + 2 * GP + 1);
     };
+#ifdef NSOF_X_PPRIO
+    if (GP == 1) __builtin_amdgcn_s_setprio(NSOF_X_PPRIO);
+#endif
     step(std::integral_constant<int, 0>{}, 0);
     __syncthreads();                                                                 // Ba
     step(std::integral_constant<int, 1>{}, 1);
@@ -350,6 +353,9 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
     // s), so the threads of the right half publish their D one window late (kept in registers meanwhile) and solve one
     // window late: lag = 1.
     const int lag = j >= G::SEG0 ? 1 : 0;
+#ifdef NSOF_X_CPRIO
+    __builtin_amdgcn_s_setprio(NSOF_X_CPRIO);
+#endif
     XT_DECL(xt && j == 0);
     double Dreg[4][5];
     // step s: four more rows enter the windows of this thread's two columns -> Dreg
