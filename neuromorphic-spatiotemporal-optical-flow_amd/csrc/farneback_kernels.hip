@@ -539,6 +539,96 @@ __global__ __launch_bounds__(256) void k_prep_direct(const uint8_t* __restrict__
     g.dst[(size_t)dy * wk + dx] = NSOF_MADD(t0, b0, t1 * b1);
 }
 
+// Resampled level, walking: thread <-> destination column, a wave walks a segment of destination rows top to bottom.
+// The direct kernel above recomputes, for EVERY destination pixel, the row filter of its KS+1 source rows (one or more
+// unaligned dword loads each); consecutive destination rows of a column share most of those rows.  Here a thread keeps the
+// row-filtered values of its two sampled columns for a window of KS+1 source rows in registers (H0 / H1, shifted as the
+// window advances -- by 1 or 2 rows per destination row at pyr_scale 0.6, 4-5 at level 3) and loads / row-filters every
+// source row ONCE: 1.7 instead of 4 row evaluations per destination pixel at level 1, 4.6 instead of 10 at level 3.  The
+// advance loop is wave-uniform (source rows depend on the destination row only).  Same helper functions and operation
+// order as the direct kernel -> bit-identical output.  Parameter sets B / C (pyr_scale 0.6): levels 1 and 2 (3 / 5 taps).
+template <int KS>
+__global__ __launch_bounds__(256) void k_prep_walk(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                    ptrdiff_t img_stride, int W, int H, int wk, int hk, double scale_x,
+                                                    double scale_y, int seg_rows, nsof_blur_taps t, float* __restrict__ out)
+{
+    constexpr int R = KS / 2, NB = KS + 1, ND = (NB + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dy0 = (blockIdx.y * 4 + wave) * seg_rows;
+    if (dy0 >= hk) return;                                        // wave-uniform
+    const int dxr = blockIdx.x * 64 + lane;
+    const bool live = dxr < wk;
+    const int dx = live ? dxr : wk - 1;
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    float* dst = out + (size_t)blockIdx.z * wk * hk;
+    int sx;
+    float a1;
+    lin_coord_x(dx, scale_x, W, sx, a1);
+    const float a0 = 1.f - a1;
+    const int c0 = sx, c1 = min(sx + 1, W - 1);
+    const bool fast = c0 - R >= 0 && c0 - R + 4 * ND <= W && c1 == c0 + 1;
+    auto tk = [&](int j) { return t.k[j]; };   // j is a compile-time constant after unrolling
+    // row-filtered values of source row rr (any integer: reflected) at columns c0 and c1
+    auto hrow = [&](int rr, float& h0, float& h1) {
+        const uint8_t* rowp = img + (ptrdiff_t)reflect101(rr, H) * row_stride;
+        float b[NB], bb[NB];
+        if (fast) {
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                unsigned v;
+                __builtin_memcpy(&v, rowp + (c0 - R) + 4 * d, 4);   // unaligned dword load
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (4 * d + e < NB) b[4 * d + e] = (float)((v >> (8 * e)) & 0xffu);
+            }
+            h0 = row_filter<KS>(tk, KS, R, [&](int c) { return b[c]; });
+            h1 = row_filter<KS>(tk, KS, R + 1, [&](int c) { return b[c]; });
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; j++) {
+                b[j] = (float)rowp[reflect101(c0 - R + j, W)];
+                bb[j] = (float)rowp[reflect101(c1 - R + j, W)];
+            }
+            h0 = row_filter<KS>(tk, KS, R, [&](int c) { return b[c]; });
+            h1 = row_filter<KS>(tk, KS, R, [&](int c) { return bb[c]; });
+        }
+    };
+    float H0[KS + 1], H1[KS + 1];
+    int base = 0;                                                  // source row of H0[0] / H1[0]
+    const int dy_end = min(dy0 + seg_rows, hk);
+    for (int dy = dy0; dy < dy_end; dy++) {
+        int sy;
+        float b1;
+        lin_coord_y(dy, scale_y, sy, b1);
+        const float b0 = 1.f - b1;
+        const int r0 = clampi(sy, 0, H - 1), r1 = clampi(sy + 1, 0, H - 1);
+        const int want = r0 - R;
+        if (dy == dy0 || want - base > KS) {                       // (re)fill the whole window
+#pragma unroll
+            for (int i = 0; i <= KS; i++) hrow(want + i, H0[i], H1[i]);
+            base = want;
+        } else {
+            while (base < want) {                                   // wave-uniform: one more source row enters
+#pragma unroll
+                for (int i = 0; i < KS; i++) { H0[i] = H0[i + 1]; H1[i] = H1[i + 1]; }
+                hrow(base + KS + 1, H0[KS], H1[KS]);
+                base++;
+            }
+        }
+        // rows of H0 / H1 are r0-R .. r0-R+KS; the window of r1 = r0+1 starts one entry later
+        const float B00 = col_filter<KS>(tk, KS, R, [&](int q) { return H0[q]; });
+        const float B01 = col_filter<KS>(tk, KS, R, [&](int q) { return H1[q]; });
+        float B10 = B00, B11 = B01;
+        if (r1 != r0) {
+            B10 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H0[q]; });
+            B11 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H1[q]; });
+        }
+        const float t0 = NSOF_MADD(B00, a0, B01 * a1);
+        const float t1 = NSOF_MADD(B10, a0, B11 * a1);
+        if (live) __builtin_nontemporal_store(NSOF_MADD(t0, b0, t1 * b1), dst + (size_t)dy * wk + dx);
+    }
+}
+
 // Resampled level, two passes (kernel sizes 9 and 19: levels 2 and 3 of the reference's parameter sets).
 // The destination samples only 2 source columns per destination column and 2 source rows per destination row,
 // so the separable blur is evaluated only there:
@@ -1627,6 +1717,24 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
                 else NSOF_DECIM(8, 19, 8);
             }
 #undef NSOF_DECIM
+        } else if (scale_x >= 1.0 && scale_y >= 1.0 && (taps.ksize == 3 || taps.ksize == 5) &&
+                   getenv("NSOF_PREP_NOWALK") == nullptr) {
+            // measured per 128-image launch at 1080p, pyr_scale 0.6: level 1 (3 taps) 656 -> 377 us, level 2 (5 taps) 407 ->
+            // 300 us against the direct kernel; with 9 taps (level 3: 415 x 233 outputs, 4.6 source rows per destination row)
+            // the walk is one long dependent chain on few waves and LOSES to the tiled kernel (985 vs 420 us): not used there
+            // segments of destination rows: long enough that the KS+1 rows of warm-up are a few per cent, short enough
+            // that a small batch still has a few thousand waves
+            int seg_rows = 32;
+            const long waves_x = (wk + 63) / 64;
+            while (seg_rows > 8 && waves_x * ((hk + seg_rows - 1) / seg_rows) * n_img < 2048) seg_rows /= 2;
+            const int nseg = (hk + seg_rows - 1) / seg_rows;
+            dim3 grid((unsigned)waves_x, (nseg + 3) / 4, n_img);
+#define NSOF_PREP_WALK(KS)                                                                                          \
+    hipLaunchKernelGGL((k_prep_walk<KS>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk, hk, \
+                       scale_x, scale_y, seg_rows, taps, out)
+            if (taps.ksize == 3) NSOF_PREP_WALK(3);
+            else NSOF_PREP_WALK(5);
+#undef NSOF_PREP_WALK
         } else if (direct_ok) {
             dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
 #define NSOF_PREP_DIRECT(KS)                                                                                       \
