@@ -285,6 +285,7 @@ def main():
                                                    kernel_ids)
         if world == 1 and not args.no_config5 and args.mode == "pairs":
             out.update(config5_leg(nsof, torch, local_rank))
+            out.update(config3_leg(nsof, torch, local_rank))
         if world == 1 and args.e2e_pairs > 0 and args.mode == "pairs":
             out.update(e2e_leg(nsof, p, prevs, nexts, flow, min(args.e2e_pairs, n), local_rank))
         if world == 1 and args.mode == "pairs" and not args.no_param_legs:
@@ -294,14 +295,14 @@ def main():
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         # one verdict over every parity record of the line: the default mode must stay within 1e-4 everywhere
-        for key in ("real_frames", "config5"):
+        for key in ("real_frames", "config5", "config3"):
             if isinstance(out.get(key), dict) and out[key].get("parity_ok") is False:
                 out["parity_ok"] = False
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if out.get("parity_ok") is False:
             print(f"bench: GPU flow differs from the CPU baseline by more than {out.get('epe_tolerance', 1e-4)} "
-                  "(headline batch, real frames or config 5)", file=sys.stderr)
+                  "(headline batch, real frames, config 3 or config 5)", file=sys.stderr)
             exit_code = 3
     if use_dist:
         dist.barrier()
@@ -446,6 +447,69 @@ def single_call_leg(nsof, _lib, ctx, torch, p, prevs, nexts, h, w, reps=20):
     rec["row_bands"]["max_abs_vs_default"] = float(np.abs(flows["row_bands"] - flows["default"]).max())
     rec["workload"] = f"one {w}x{h} pair per call"
     return rec
+
+
+def config3_leg(nsof, torch, local_rank):
+    """BASELINE config 3 joined, on one GPU (1280x720 synthetic stream, 1 ms slices, scheme 1 split,
+    active -6 V): events -> surface frames + gating maps every 33 slices -> device ROI rectangles -> Farneback (params A) on
+    every ROI crop of consecutive surface frames as one work list (pipeline.events_to_roi_flows).  Two streams: the
+    SURVEY stream as defined (200 k background events: every 20x20 block holds a recent event, so the gate opens the full
+    frame) and two sparse variants (silent 0.5 V so idle devices decay below the threshold): 5 k background events -- a few
+    hundred small ROIs per map, the many-small-crops stress of the work list -- and 300 background events, where the gate
+    leaves the moving box and little else.  Parity: the first flow canvas against the oracle chain
+    (oracle/accum_ref.c -> uint8(255 w) / block currents -> host gating mirror -> oracle/farneback_ref.c per crop)."""
+    import numpy as np
+    from nsof import gating, pipeline, synth
+    from nsof.farneback import PARAMS_A
+    from oracle import oracle as O  # noqa: N812
+    H, W, every, ms = 720, 1280, 33, 20  # noqa: N806
+    pa = [getattr(PARAMS_A, kk) for kk in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    cfg = gating.GatingConfig(MEMSIZE=ms, EXTEND_HEIGHT_UPPER=20, EXTEND_HEIGHT_LOWER=20, EXTEND_WIDTH_LEFT=20,
+                              EXTEND_WIDTH_RIGHT=20, THRES=240, FLAG=1, farneback_params=PARAMS_A)
+    _, _, _, usable = O.host_cpu()
+    nt = min(usable, 16)
+    rec = {"workload": f"events -> scheme-1 surface -> 8-bit frames + gating maps every {every} slices -> device ROI -> "
+                       f"Farneback A per ROI crop, {W}x{H}, one GPU; MEMSIZE {ms}, THRES 240, FLAG 1, extend 20 px",
+           "epe_tolerance": 1e-4, "streams": {}}
+    ok_all = True
+    with nsof.Context(local_rank) as c:
+        for name, n_bg, silent in (("survey_200k_background", 200_000, 0.0), ("sparse_5k_background", 5_000, 0.5),
+                                     ("box_only_300_background", 300, 0.5)):
+            x, y, p, t = synth.make_events(2024, W, H, n_background=n_bg)
+            tm = {}
+            kw = dict(slice_us=1000, active_v=-6.0, silent_v=silent, snapshot_every=every, ctx=c, timings=tm, max_rects=256)
+            pipeline.events_to_roi_flows(x, y, p, t, (H, W), cfg, **kw)           # warm-up
+            frames, rects, flows = pipeline.events_to_roi_flows(x, y, p, t, (H, W), cfg, **kw)
+            n_fr = tm["frames"]
+            total = tm["surface_and_gating_s"] + tm["flow_s"]
+            # first pair against the oracle chain
+            ws = [O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, silent, n_slices=(k + 1) * every, n_threads=nt)[1] for k in range(2)]
+            f = [(np.float32(255.0) * w).astype(np.uint8) for w in ws]
+            gfr = frames[:2].cpu().numpy()
+            frames_equal = bool(np.array_equal(gfr[0], f[0]) and np.array_equal(gfr[1], f[1]))
+            g = gating.current_to_gray(pipeline.surface_to_block_current(O.accum_resistance(ws[1]), ms))
+            tp = gating.update_transition_pic(g, np.zeros_like(g, dtype=np.float64), cfg.THRES).astype(np.uint8)
+            n, _, stats, _ = gating.connectedComponentsWithStats(tp, cfg.CONNECT)
+            want = [gating._roi(*[int(v) for v in stats[i, :4]], W, H, ms, ms, cfg) for i in range(1, n)]
+            canvas = np.zeros((H, W, 2), np.float32)
+            for (x0, y0, x1, y1) in want:
+                canvas[y0:y1, x0:x1] = O.farneback(np.ascontiguousarray(f[0][y0:y1, x0:x1]),
+                                                   np.ascontiguousarray(f[1][y0:y1, x0:x1]), *pa)
+            got = flows[0].cpu().numpy()
+            d = float(np.abs(got - canvas).max())
+            ok = frames_equal and rects[1] == want and d < 1e-4
+            ok_all &= ok
+            rec["streams"][name] = {
+                "events": int(len(t)), "silent_v": silent, "frames": n_fr, "roi_calls": tm["roi_calls"],
+                "roi_pixel_fraction": round(tm["roi_pixels"] / float((n_fr - 1) * H * W), 4),
+                "surface_and_gating_ms": round(tm["surface_and_gating_s"] * 1e3, 2), "flow_ms": round(tm["flow_s"] * 1e3, 2),
+                "flow_fields_per_s": round((n_fr - 1) / total, 1), "x_realtime": round(n_fr * every * 1e-3 / total, 1),
+                "first_pair_vs_oracle_chain": {"surface_frames_equal": frames_equal, "rects_equal": bool(rects[1] == want),
+                                               "rects": len(want), "max_abs_epe_vs_oracle": d,
+                                               "bit_identical": bool(np.array_equal(got, canvas))},
+                "parity_ok": bool(ok)}
+    rec["parity_ok"] = bool(ok_all)
+    return {"config3": rec}
 
 
 def config5_leg(nsof, torch, local_rank):

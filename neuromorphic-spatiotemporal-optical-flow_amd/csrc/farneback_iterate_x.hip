@@ -399,7 +399,11 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
     for (int t = 0; t <= nimg + 1; t++) {
         XT_MARK(1);        // wait at the barrier
         const int u = t - 1 - lag;   // the step whose g the scanner completed in the last window
+#ifdef NSOF_X_ABL_SOLVE   // timing-only ablation: no solve at all
+        if (false) {
+#else
         if (u >= 0 && u < nimg && x < W) {
+#endif
             const double* svj = sv + (u & 1) * (G::SV1_BYTES / sizeof(double)) + j;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -672,7 +676,25 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
         FlowSrc<false> F;
         F.base = reinterpret_cast<const char*>(flow_in) + (HET ? 0 : (size_t)pair * plane * 8);
         F.W = (unsigned)W;
-        if (pw == G::NB) {
+        // wave -> role.  Waves go to SIMD (wave % 4).  NSOF_X_WAVEMAP=1: the light I/O wave shares SIMD 1 with the middle
+        // consumer wave (the one that publishes both halves, the longest of a step) and a rows-2,3 producer moves next to
+        // the scanner on SIMD 3: waves 4-6 rows 0,1 of blocks 0-2; 7 rows 2,3 of block 1; 8 rows 2,3 of block 0; 9 I/O; 10
+        // rows 2,3 of block 2.  Default (0): 4-6 rows 0,1; 7 I/O; 8-10 rows 2,3.
+#ifndef NSOF_X_WAVEMAP
+#define NSOF_X_WAVEMAP 0
+#endif
+        bool is_io;
+        int gp, blk;
+        if (NSOF_X_WAVEMAP == 1) {
+            is_io = pw == 5;
+            gp = pw < 3 ? 0 : 1;
+            blk = pw < 3 ? pw : (pw == 3 ? 1 : (pw == 4 ? 0 : 2));
+        } else {
+            is_io = pw == G::NB;
+            gp = pw < G::NB ? 0 : 1;
+            blk = pw < G::NB ? pw : pw - G::NB - 1;
+        }
+        if (is_io) {
             const int col = G::NB * 64 + (lane & 15), r = lane >> 4;
             const int xc = clampi(x0 - MH - 1 + col, 0, W - 1);
             F.xc = (unsigned)xc;
@@ -681,11 +703,10 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
             gu64* cout = x0 + SW < W ? cbase + (size_t)strip * per_strip : nullptr;
             x_remainder_loop<MH>(ring, cb, R0, R1, F, W, H, xc, col, r, nimg, cin, cout, epoch, (gu32*)err, xt);
         } else {
-            const int blk = pw < G::NB ? pw : pw - G::NB - 1;
             const int col = blk * 64 + lane;
             const int xc = clampi(x0 - MH - 1 + col, 0, W - 1);
             F.xc = (unsigned)xc;
-            if (pw < G::NB)
+            if (gp == 0)
                 x_producer_loop<MH, 0>(ring, R0, R1, F, W, H, xc, col, nimg, xt && blk == 0);
             else
                 x_producer_loop<MH, 1>(ring, R0, R1, F, W, H, xc, col, nimg, xt && blk == 0);

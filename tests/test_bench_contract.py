@@ -46,6 +46,11 @@ def test_bench_json_contract():
     # round 3: the library's row-sum order is the default -> the headline batch, the reference's real frames and the first
     # pair of the joined config-5 pipeline are all bit-identical to the oracle; the per-pixel sums are a named fast mode
     assert "library order" in d["config"]["rowsum_order"] and d["bit_identical_to_oracle"] is True
+    c3 = d["config3"]
+    assert c3["parity_ok"] is True and len(c3["streams"]) == 3
+    for srec in c3["streams"].values():
+        assert srec["first_pair_vs_oracle_chain"]["bit_identical"] is True and srec["flow_fields_per_s"] > 0
+    assert c3["streams"]["survey_200k_background"]["roi_pixel_fraction"] == 1.0
     c5 = d["config5"]
     assert c5["parity_ok"] is True and c5["first_pair_vs_oracle_chain"]["surface_frames_equal"] is True
     assert c5["first_pair_vs_oracle_chain"]["default"]["max_abs_epe_vs_oracle"] < 1e-4

@@ -324,3 +324,50 @@ def test_events_to_rois_device_path_equals_host_path(nsof_lib, ctx):
             want = rb if flag == 1 else ([(min(r[0] for r in rb), min(r[1] for r in rb), max(r[2] for r in rb), max(r[3] for r in rb))] if rb else [])
             assert ra == want
         assert any(len(r) for _, r in a)
+
+
+@pytest.mark.gpu
+def test_config3_roi_flow_pipeline_vs_oracle_chain(nsof_lib, ctx, oracle):
+    """BASELINE config 3 joined on the device (pipeline.events_to_roi_flows: events -> surface frames + gating maps ->
+    device ROI rectangles -> flow of every ROI crop as one work list, pasted into zero canvases) against the oracle
+    CHAIN: oracle/accum_ref.c for the slices -> uint8(255 w) frames and V_ds / resistance block maxima -> the host mirror
+    of the reference's gating (current -> gray, threshold, components, boxes) -> oracle/farneback_ref.c on each crop,
+    pasted in label order.  Frames byte-identical, rectangles identical, flow canvases bit-identical; both FLAG modes."""
+    from nsof import gating, pipeline, synth
+    from nsof.farneback import PARAMS_B
+    H, W, every = 240, 320, 40   # noqa: N806
+    x, y, p, t = synth.make_events(7, W, H, n_background=3000, duration_us=160_000, box=(40, 30), speed_pps=500.0)
+    pb = [getattr(PARAMS_B, k) for k in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    ref_frames, ref_cur = [], []
+    for k in range(4):
+        _, w = oracle.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.5, n_slices=(k + 1) * every, n_threads=4)
+        ref_frames.append((np.float32(255.0) * w).astype(np.uint8))
+        ref_cur.append(pipeline.surface_to_block_current(oracle.accum_resistance(w), 20))
+    some_overlap = False
+    for flag in (1, 2):
+        cfg = gating.GatingConfig(MEMSIZE=20, EXTEND_HEIGHT_UPPER=10, EXTEND_HEIGHT_LOWER=10, EXTEND_WIDTH_LEFT=10,
+                                  EXTEND_WIDTH_RIGHT=10, THRES=240, FLAG=flag, farneback_params=PARAMS_B)
+        tm = {}
+        frames, rects, flows = pipeline.events_to_roi_flows(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5,
+                                                            snapshot_every=every, ctx=ctx, timings=tm)
+        gf, gfl = frames.cpu().numpy(), flows.cpu().numpy()
+        assert gf.shape == (4, H, W) and gfl.shape == (3, H, W, 2) and tm["roi_calls"] >= 1
+        for k in range(4):
+            assert np.array_equal(gf[k], ref_frames[k]), k
+            g = gating.current_to_gray(ref_cur[k])
+            tp = gating.update_transition_pic(g, np.zeros_like(g, dtype=np.float64), cfg.THRES).astype(np.uint8)
+            n, _, stats, _ = gating.connectedComponentsWithStats(tp, cfg.CONNECT)
+            want = [gating._roi(*[int(v) for v in stats[i, :4]], W, H, 20, 20, cfg) for i in range(1, n)]
+            if flag == 2 and want:
+                want = [(min(r[0] for r in want), min(r[1] for r in want), max(r[2] for r in want), max(r[3] for r in want))]
+            assert rects[k] == want, (flag, k, rects[k], want)
+        for k in range(3):
+            canvas = np.zeros((H, W, 2), np.float32)
+            done = []
+            for (x0, y0, x1, y1) in rects[k + 1]:
+                canvas[y0:y1, x0:x1] = oracle.farneback(np.ascontiguousarray(ref_frames[k][y0:y1, x0:x1]),
+                                                        np.ascontiguousarray(ref_frames[k + 1][y0:y1, x0:x1]), *pb)
+                some_overlap |= any(x0 < b[2] and b[0] < x1 and y0 < b[3] and b[1] < y1 for b in done)
+                done.append((x0, y0, x1, y1))
+            assert np.array_equal(gfl[k], canvas), (flag, k, float(np.abs(gfl[k] - canvas).max()))
+        assert any(len(r) for r in rects[1:])
