@@ -175,13 +175,19 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
         const size_t szI = align_up(maxI * 4, 256), szR = align_up(maxR * 4, 256), szF = align_up(maxF * 8, 256);
         static const bool exact_2k = [] { const char* e = getenv("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
         const bool exact_x = exact && !exact_2k;   // one fused kernel (k_iterate_x); 2k: column sums through HBM
-        const size_t szV = exact && !exact_x ? szR : 0;   // two-kernel exact order: column sums, 5 doubles per pixel = the expansion's footprint
-        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + 2 * szF + szV))) return rc;
+        // a list too small to fill the chip with (strip, item) jobs: the three-kernel small-batch form of the same order
+        long long jobs = 0;
+        for (int j = 0; j < nh; j++) jobs += (descs[het[j]].width + 191) / 192;
+        const bool exact_lat = exact_x && jobs <= ctx->opt_small_batch_jobs;
+        const size_t szV = (exact && !exact_x) || exact_lat ? szR : 0;   // column sums, 5 doubles per pixel = the expansion's footprint
+        const size_t szM = exact_lat ? align_up(szR / 2, 256) : 0;        // matrices of the small-batch form, 5 floats per pixel
+        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + 2 * szF + szV + szM))) return rc;
         char* base = (char*)ctx->ws;
         float* dI = (float*)base;
         float* dR = (float*)(base + szI);
         float* fb[2] = {(float*)(base + szI + szR), (float*)(base + szI + szR + szF)};
         double* dV = (double*)(base + szI + szR + 2 * szF);
+        float* dM = (float*)(base + szI + szR + 2 * szF + szV);
         int cur = 0;
         for (int k = Lmax; k >= 0; k--) {
             int wk, hk, ks;
@@ -202,7 +208,10 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
             if ((rc = nsof_launch_polyexp_het(ctx, nk_items, dt, max_w[k], max_h[k], ptaps, dI, dR))) return rc;
             for (int it = 0; it < p.iterations; it++) {
                 const bool final = k == 0 && it == p.iterations - 1;
-                if (exact_x)
+                if (exact_lat)
+                    rc = nsof_launch_iterate_lat_het(ctx, nk_items, dt, max_w[k], max_h[k], dR, fb[cur], fb[cur ^ 1], final, p.winsize,
+                                                     dM, dV);
+                else if (exact_x)
                     rc = nsof_launch_iterate_x_het(ctx, nk_items, dt, max_w[k], max_h[k], dR, szR / 4, fb[cur], fb[cur ^ 1], final,
                                                    p.winsize);
                 else if (exact)

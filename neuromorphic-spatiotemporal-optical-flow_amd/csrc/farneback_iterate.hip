@@ -1285,6 +1285,28 @@ int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
 
 // Exact-order twin of nsof_launch_iterate: phase A (fused matrix update + column sums -> vsum) and phase B (row scan
 // + solve).  vsum: n_pairs * 5 * W * H doubles of scratch.  winsize 2..15.
+// Phase B on its own (the small-batch form, farneback_iterate_lat.hip, forms the column sums with its own kernels).
+int nsof_launch_rowscan_solve(nsof_ctx* ctx, int n_pairs, const double* V, int W, int H, int winsize, float* flow_out)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    if (int rc = lds_opt_in(ctx, k_rowscan_solve, RS_SMEM)) return rc;
+    hipLaunchKernelGGL(k_rowscan_solve, dim3((H + RS_ROWS - 1) / RS_ROWS, 1, n_pairs), dim3(RS_THREADS), RS_SMEM, ctx->stream, V,
+                       W, H, winsize / 2, winsize, flow_out, (size_t)W, nullptr, 0);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int nsof_launch_rowscan_solve_het(nsof_ctx* ctx, int n_items, const nsof_het_item* items, int max_h, const double* V,
+                                  float* flow_out, bool final, int winsize)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    if (int rc = lds_opt_in(ctx, k_rowscan_solve, RS_SMEM)) return rc;
+    hipLaunchKernelGGL(k_rowscan_solve, dim3((max_h + RS_ROWS - 1) / RS_ROWS, 1, n_items), dim3(RS_THREADS), RS_SMEM, ctx->stream,
+                       V, 0, 0, winsize / 2, winsize, flow_out, (size_t)0, items, final ? 1 : 0);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
 bool nsof_iterate_exact_supported(int winsize, int W, int H)
 {
     const int m = winsize / 2;

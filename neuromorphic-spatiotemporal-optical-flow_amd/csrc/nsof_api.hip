@@ -222,6 +222,7 @@ extern "C" int nsof_create(int device, nsof_ctx** out)
     if (const char* e = getenv("NSOF_POLYEXP_F32")) ctx->opt_polyexp_f32 = (e[0] && e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("NSOF_EXACT_ROWSUMS")) ctx->opt_exact_rowsums = (e[0] && e[0] != '0') ? 1 : 0;
     if (const char* e = getenv("NSOF_PYR_FMA")) ctx->opt_pyr_fma = (e[0] && e[0] != '0') ? 1 : 0;
+    if (const char* e = getenv("NSOF_LAT_JOBS")) ctx->opt_small_batch_jobs = atoi(e) < 0 ? 0 : atoi(e);
     if (const char* e = getenv("NSOF_ROW_BANDS")) {
         const int v = atoi(e);
         ctx->opt_row_bands = v < 0 || v == 2 || v == 3 ? 0 : v;
@@ -280,6 +281,11 @@ extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
         ctx->opt_row_bands = value;
         return NSOF_OK;
     }
+    if (option == NSOF_OPT_SMALL_BATCH_JOBS) {
+        if (value < 0) return nsof_set_error(ctx, NSOF_EINVAL, "NSOF_OPT_SMALL_BATCH_JOBS: a job count >= 0");
+        ctx->opt_small_batch_jobs = value;
+        return NSOF_OK;
+    }
     return nsof_set_error(ctx, NSOF_EINVAL, "unknown option %d", option);
 }
 
@@ -300,6 +306,10 @@ extern "C" int nsof_get_option(const nsof_ctx* ctx, int option, int* value)
     }
     if (option == NSOF_OPT_PYR_FMA) {
         *value = ctx->opt_pyr_fma;
+        return NSOF_OK;
+    }
+    if (option == NSOF_OPT_SMALL_BATCH_JOBS) {
+        *value = ctx->opt_small_batch_jobs;
         return NSOF_OK;
     }
     return NSOF_EINVAL;
@@ -585,6 +595,9 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     static const char* fused_env0 = getenv("NSOF_FUSED");
     const bool exact_x = exact && !exact_2k && !(fused_env0 && fused_env0[0] == '0') && iterations > 0 &&
                          nsof_iterate_x_supported(winsize, width, height);
+    // a batch too small to fill the chip with (strip, image) jobs takes the three-kernel small-batch form of the same
+    // order (farneback_iterate_lat.hip; NSOF_OPT_SMALL_BATCH_JOBS)
+    const bool exact_lat = exact_x && (long long)n_pairs * ((width + 191) / 192) <= ctx->opt_small_batch_jobs;
     static const int exact_chunk = [] {
         const char* e = getenv("NSOF_EXACT_CHUNK");
         const int v = e ? atoi(e) : 64;
@@ -609,7 +622,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         // + 20 / 40 B/px of matrices / column sums in the unfused / exact forms) would not fit the device's free memory is run in chunks of as many pairs as do
         // fit -- same kernels on sub-ranges of the same buffers, so the result does not depend on the chunking.
         // NSOF_MAX_PAIRS caps the chunk by hand (tests).
-        const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact && !exact_x ? 40 : 0)) + 4096;
+        const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact && !exact_x ? 40 : 0) + (exact_lat ? 60 : 0)) + 4096;
         size_t fit = ctx->ws_bytes / per_pair;   // what the workspace already holds needs no query (lone calls stay cheap)
         if ((size_t)n_pairs > fit) {
             size_t free_b = 0, total_b = 0;
@@ -651,8 +664,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0') &&
                        (!exact || exact_fused);
     const size_t szI = align_up(n_img * n0 * 4, 256), szR = align_up(n_img * 5 * n0 * 4, 256);
-    const size_t szS = align_up(B * n0 * 8, 256), szM = fused ? 0 : align_up(B * 5 * n0 * 4, 256);
-    const size_t szV = exact && !exact_x ? align_up(B * 5 * n0 * 8, 256) : 0;   // column sums of the two-kernel exact order
+    const size_t szS = align_up(B * n0 * 8, 256), szM = fused && !exact_lat ? 0 : align_up(B * 5 * n0 * 4, 256);
+    const size_t szV = (exact && !exact_x) || exact_lat ? align_up(B * 5 * n0 * 8, 256) : 0;   // column sums of the two- / three-kernel exact order
     if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, szI + szR + szS + szM + szV))) return rc;
     char* base = (char*)ctx->ws;   // (re-derived below if the level overlap grows the workspace)
     float* dI = (float*)base;
@@ -801,6 +814,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
                 if (it == 0 && pending_ups)
                     rc = nsof_launch_iterate_upsample(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], pw, ph,
                                                       (float)(1. / pyr_scale), fb[cur ^ 1], wk, hk, winsize);
+                else if (exact_lat)
+                    rc = nsof_launch_iterate_lat(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize, dM, dV);
                 else if (exact_x)
                     rc = nsof_launch_iterate_x(ctx, n_pairs, R0, R1, 5 * nk, fb[cur], fb[cur ^ 1], wk, hk, winsize);
                 else if (exact_fused)

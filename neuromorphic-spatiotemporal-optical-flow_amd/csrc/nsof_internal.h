@@ -27,6 +27,7 @@ struct nsof_ctx {
     int opt_polyexp_f32 = 0;   // NSOF_OPT_POLYEXP_F32
     int opt_exact_rowsums = 1; // NSOF_OPT_EXACT_ROWSUMS (default: the library's row-sum order)
     int opt_row_bands = 0;     // NSOF_OPT_ROW_BANDS: 0 off, 1 automatic, >= 4 rows per band
+    int opt_small_batch_jobs = 256;   // NSOF_OPT_SMALL_BATCH_JOBS: calls with at most this many (strip, image) jobs take the three-kernel exact form
     int opt_pyr_fma = 0;       // NSOF_OPT_PYR_FMA: pyramid blur / resamples with fused multiply-adds (arithmetic variant twin)
     char err[512] = {0};
     // reusable device workspace of the Farneback driver
@@ -135,6 +136,15 @@ struct nsof_het_item {
 };
 enum { NSOF_HET_VEC0 = 1 };
 
+// Small-batch exact-order iteration (farneback_iterate_lat.hip): matrices, column sums and row scan as three wide kernels.
+// M: 5 floats, V: 5 doubles per pixel of the level (work list: at offR / 2 of each item).  winsize 2..15.
+int nsof_launch_iterate_lat(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
+                            const float* flow_in, float* flow_out, int W, int H, int winsize, float* M, double* V);
+int nsof_launch_iterate_lat_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
+                                const float* flow_in, float* flow_out, bool final, int winsize, float* M, double* V);
+int nsof_launch_rowscan_solve(nsof_ctx* ctx, int n_pairs, const double* V, int W, int H, int winsize, float* flow_out);
+int nsof_launch_rowscan_solve_het(nsof_ctx* ctx, int n_items, const nsof_het_item* items, int max_h, const double* V,
+                                  float* flow_out, bool final, int winsize);
 int nsof_launch_iterate_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
                                   const float* R, const float* flow_in, float* flow_out, bool final, int winsize,
                                   double* vsum);

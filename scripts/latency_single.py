@@ -16,8 +16,11 @@ from nsof import _lib  # noqa: E402
 
 ctx = nsof.Context(0)
 BANDS = [int(v) for v in os.environ.get("BANDS", "0,1").split(",")]   # values of NSOF_OPT_ROW_BANDS to time
-for (h, w, name, p) in [(1080, 1920, "1080p full frame, params A", PARAMS_A), (200, 520, "520x200 ROI, params A", PARAMS_A),
-                        (801, 801, "801x801 autodriving frame, params B", PARAMS_B), (161, 161, "161x161 uav, params B", PARAMS_B)]:
+CASES = [(1080, 1920, "1080p full frame, params A", PARAMS_A), (200, 520, "520x200 ROI, params A", PARAMS_A),
+         (801, 801, "801x801 autodriving frame, params B", PARAMS_B), (161, 161, "161x161 uav, params B", PARAMS_B)]
+if os.environ.get("SHAPES"):
+    CASES = [CASES[int(v)] for v in os.environ["SHAPES"].split(",")]
+for (h, w, name, p) in CASES:
   prev, nxt = synth.make_pair(1, h, w)
   kw = p.as_kwargs()
   base = None

@@ -614,3 +614,38 @@ def test_pyramid_fma_variant_twin(nsof_lib, ctx, oracle, torch_dev):
     for name in "ABC":
         d = float(np.abs(res[(0, name)] - res[(1, name)]).max())
         assert 0 < d < 5e-3, (name, d)
+
+
+@pytest.mark.gpu
+def test_small_batch_form_is_bit_identical_to_fused_kernel(nsof_lib, ctx, oracle):
+    """NSOF_OPT_SMALL_BATCH_JOBS: calls with few (strip, image) jobs run the exact-order iteration as three wide kernels
+    (matrices / column sums / row scan + solve, farneback_iterate_lat.hip) instead of the fused strip walker -- same
+    arithmetic, same order: both forms equal the oracle bit for bit, lone calls and ROI work lists, every window
+    the fused kernel covers, ragged and tiny sizes included."""
+    from nsof import _lib, synth
+    assert ctx.get_option(_lib.OPT_SMALL_BATCH_JOBS) == 256
+    cases = [((135, 240), A), ((200, 303), B), ((97, 131), Cc), ((33, 17), (0.5, 2, 5, 2, 5, 1.1, 0)),
+             ((70, 450), (0.6, 3, 15, 2, 7, 1.5, 0)), ((257, 64), (0.5, 1, 2, 3, 5, 1.2, 0)), ((16, 16), (0.5, 0, 9, 1, 5, 1.1, 0)),
+             ((540, 960), A)]
+    try:
+        for k, (shape, params) in enumerate(cases):
+            prev, nxt = synth.make_pair(60 + k, *shape)
+            want = oracle.farneback(prev, nxt, *params)
+            for jobs in (0, 256):
+                ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, jobs)
+                got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
+                assert np.array_equal(got, want), (shape, params, jobs, float(np.abs(got - want).max()))
+        # a ragged ROI work list (the gated path's calls) in both forms
+        big_p, big_n = synth.make_pair(77, 400, 600)
+        rects = [(0, 0, 600, 400), (10, 20, 210, 140), (301, 7, 364, 390), (100, 100, 133, 121), (17, 250, 590, 399)]
+        pairs = [(big_p[y0:y1, x0:x1], big_n[y0:y1, x0:x1]) for (x0, y0, x1, y1) in rects]
+        ref = [oracle.farneback(np.ascontiguousarray(a), np.ascontiguousarray(b), *B) for a, b in pairs]
+        for jobs in (0, 256):
+            ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, jobs)
+            flows = nsof_lib.farneback_pairs(pairs, nsof_lib.farneback.PARAMS_B, ctx=ctx)
+            for f, r in zip(flows, ref):
+                assert np.array_equal(f, r), jobs
+        with pytest.raises(nsof_lib.NsofError):
+            ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, -1)
+    finally:
+        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 256)
