@@ -443,6 +443,31 @@ def single_call_leg(nsof, _lib, ctx, torch, p, prevs, nexts, h, w, reps=20):
             ctx.set_option(_lib.OPT_ROW_BANDS, 0)
             ctx.set_option(_lib.OPT_EXACT_ROWSUMS, 1)
         rec[key] = {"host_to_host_ms": round(host_ms, 3), "device_resident_ms": round(dev_ms, 3), "kernel_ms": parts}
+    # the same lone call forced through the fused strip walker (NSOF_OPT_SMALL_BATCH_JOBS=0): what the small-batch form buys
+    ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 0)
+    try:
+        for _ in range(3):
+            fx = nsof.calcOpticalFlowFarneback(hp, hn, None, **kw, ctx=ctx)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            nsof.calcOpticalFlowFarneback(hp, hn, None, **kw, ctx=ctx)
+        rec["default_fused_kernel_only"] = {"host_to_host_ms": round((time.perf_counter() - t0) / reps * 1e3, 3),
+                                            "option": "NSOF_OPT_SMALL_BATCH_JOBS=0",
+                                            "max_abs_vs_default": float(np.abs(fx - flows["default"]).max())}
+    finally:
+        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 64)
+    rec["default"]["form"] = ("three wide kernels per iteration (calls with <= 64 strip jobs, NSOF_OPT_SMALL_BATCH_JOBS), "
+                              "bit-identical to the fused kernel")
+    from nsof import synth
+    from nsof.farneback import PARAMS_B
+    bp, bn = synth.make_pair(5, 801, 801)
+    kb = PARAMS_B.as_kwargs()
+    for _ in range(3):
+        nsof.calcOpticalFlowFarneback(bp, bn, None, **kb, ctx=ctx)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        nsof.calcOpticalFlowFarneback(bp, bn, None, **kb, ctx=ctx)
+    rec["default_801x801_params_B"] = {"host_to_host_ms": round((time.perf_counter() - t0) / reps * 1e3, 3)}
     rec["row_bands"]["option"] = "NSOF_OPT_ROW_BANDS=1 (opt-in; column sums restart per band)"
     rec["row_bands"]["max_abs_vs_default"] = float(np.abs(flows["row_bands"] - flows["default"]).max())
     rec["workload"] = f"one {w}x{h} pair per call"

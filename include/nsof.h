@@ -81,13 +81,14 @@ int nsof_synchronize(nsof_ctx* ctx);
  * build of the library's vector loops contracts them.  Which of the two a given cv2 wheel executes cannot be pinned in
  * this image (DESIGN.md section 2 states how far the flow moves between them); both equal their CPU restatement
  * (oracle build of the same switch) bit for bit.  Environment default: NSOF_PYR_FMA. */
-/* NSOF_OPT_SMALL_BATCH_JOBS (default 256; exact row-sum order only): the fused iteration kernel gives one workgroup a
- * (192-column strip, image) job and walks the image height in it; a call with fewer jobs than this -- a lone frame pair
- * (10 jobs at 1920 wide), a few ROI crops: the reference's own call pattern -- leaves most of the 256 compute units
- * idle, so such calls run the SAME arithmetic in the SAME order as three wide kernels (matrices; column sums, one thread
- * per column and plane; row sums + solve, one thread per row and plane) with the intermediates in HBM.  Results are
- * bit-identical either way; the value only moves the switch-over (0 = always the fused kernel).  Environment default:
- * NSOF_LAT_JOBS. */
+/* NSOF_OPT_SMALL_BATCH_JOBS (default 64; exact row-sum order only): the fused iteration kernel gives one workgroup a
+ * (192-column strip, image) job and walks the image height in it; a call with at most this many jobs -- a lone frame
+ * pair (10 jobs at 1920 wide), a few ROI crops: the reference's own call pattern -- leaves most of the 256 compute
+ * units idle, so such calls run the SAME arithmetic in the SAME order as three wide kernels per iteration (matrices;
+ * column sums, one thread per column and plane; row sums + solve, one thread per row and plane) with the intermediates
+ * in HBM: a lone 1920x1080 call 3.9 -> 1.4 ms host to host.  Results are bit-identical either way; the value only moves
+ * the switch-over (measured cross-over: 70-80 jobs, scripts/small_batch_crossover.py; 0 = always the fused kernel).
+ * Environment default: NSOF_LAT_JOBS. */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3, NSOF_OPT_PYR_FMA = 4,
        NSOF_OPT_SMALL_BATCH_JOBS = 5 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);

@@ -177,7 +177,10 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
         const bool exact_x = exact && !exact_2k;   // one fused kernel (k_iterate_x); 2k: column sums through HBM
         // a list too small to fill the chip with (strip, item) jobs: the three-kernel small-batch form of the same order
         long long jobs = 0;
-        for (int j = 0; j < nh; j++) jobs += (descs[het[j]].width + 191) / 192;
+        for (int j = 0; j < nh; j++) {
+            jobs += (descs[het[j]].width + 191) / 192;
+            if ((unsigned long long)descs[het[j]].width * descs[het[j]].height * 40ull >= (1ull << 32)) jobs = 1ll << 40;   // 32-bit offsets per item
+        }
         const bool exact_lat = exact_x && jobs <= ctx->opt_small_batch_jobs;
         const size_t szV = (exact && !exact_x) || exact_lat ? szR : 0;   // column sums, 5 doubles per pixel = the expansion's footprint
         const size_t szM = exact_lat ? align_up(szR / 2, 256) : 0;        // matrices of the small-batch form, 5 floats per pixel

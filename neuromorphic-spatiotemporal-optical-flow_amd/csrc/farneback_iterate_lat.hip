@@ -7,7 +7,7 @@
 // three kernels, each as wide as its step allows, with the intermediates in HBM (they stay in the 256 MB MALL):
 //   k_lat_matrices   thread <-> pixel          FarnebackUpdateMatrices                       M [5][h][w] f32
 //   k_lat_colsum     thread <-> (column, plane) the library's running column sums, top down   V [h][5][w] f64
-//   k_rowscan_solve  thread <-> (row, plane)    the library's running row sums + 2x2 solve    (farneback_iterate.hip)
+//   k_lat_rowscan    thread <-> (row, plane)    the library's running row sums, pipelined with the 2x2 solve of the previous tile
 // Same arithmetic, same order, same bits as k_iterate_x (upstream FarnebackUpdateFlow_Blur, optflowgf.cpp); 60 B/px of extra HBM traffic, which is why large batches keep the fused kernel.
 #include <hip/hip_runtime.h>
 
@@ -51,50 +51,283 @@ __global__ __launch_bounds__(256) void k_lat_matrices(const float* __restrict__ 
 
 // The library's column sums (FarnebackUpdateFlow_Blur's vsum rows): vsum = float(M[0] * (m + 2)), += M[y] for y = 1..m-1,
 // then per row += double(float(M[y + m] - M[y - m - 1])) with replicated borders.  One double addition per row is the
-// whole recurrence; the loads and float differences of LAT_U rows are formed ahead of it (two register sets).
-constexpr int LAT_U = 16;
+// whole recurrence (~10 clocks); what a lone wave cannot do is keep enough rows in flight -- a wave may have 64 memory
+// operations outstanding (vmcnt), ~20 rows against ~2000 clocks of latency.  So the 16 waves of a workgroup take turns:
+// wave k owns rows [24 k, 24 k + 24) of every 384-row pass, has their loads in flight long before its turn, adds them to
+// the running sums handed over through LDS, and requests its rows of the next pass.
+constexpr int LC_WAVES = 16, LC_R = 24, LC_PASS = LC_WAVES * LC_R;
 template <bool HET>
-__global__ __launch_bounds__(64) void k_lat_colsum(const float* __restrict__ M, int W, int H, int m, double* __restrict__ V,
-                                                    const nsof_het_item* __restrict__ items)
+__global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __restrict__ M, int W, int H, int m,
+                                                               double* __restrict__ V, const nsof_het_item* __restrict__ items)
 {
+    __shared__ double carry[64];
     if constexpr (HET) {
         const nsof_het_item& it = items[blockIdx.z];
         W = it.wk;
         H = it.hk;
+        if (blockIdx.x * 64 >= W) return;   // block-uniform, before any barrier
         M += it.offR / 2;
         V += it.offR / 2;
     } else {
         M += (size_t)blockIdx.z * 5 * W * H;
         V += (size_t)blockIdx.z * 5 * W * H;
     }
-    const int x = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y;
-    if (x >= W) return;
-    const float* Mc = M + (size_t)c * W * H + x;
-    double* Vc = V + (size_t)c * W + x;          // V[(y * 5 + c) * W + x]
-    const size_t vrow = (size_t)5 * W;
-    double vs = (double)(Mc[0] * (float)(m + 2));
-    for (int y = 1; y < m; y++) vs += (double)Mc[(size_t)min(y, H - 1) * W];
-    float d[LAT_U], nd[LAT_U];
-    auto fetch = [&](int y0, float (&o)[LAT_U]) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + lane, c = blockIdx.y;
+    const bool live = x < W;                                  // lanes beyond the image load a clamped column and store nothing
+    // wave-uniform bases + 32-bit byte offsets (the launcher checks 40 W H < 4 GB): one VALU add per address
+    const char* mb = reinterpret_cast<const char*>(M + (size_t)c * W * H);
+    char* vb = reinterpret_cast<char*>(V + (size_t)c * W);   // V[(y * 5 + c) * W + x]
+    const unsigned xm = 4u * (unsigned)min(x, W - 1), xv = 8u * (unsigned)x;
+    const unsigned mrow = 4u * (unsigned)W, vrow = 40u * (unsigned)W;
+    auto Mat = [&](int row) { return *reinterpret_cast<const float*>(mb + ((unsigned)row * mrow + xm)); };
+    float a[LC_R], b[LC_R];
+    auto fetch = [&](int y0) {
+        if (y0 - m - 1 >= 0 && y0 + LC_R + m <= H) {          // interior rows: no clamps
 #pragma unroll
-        for (int j = 0; j < LAT_U; j++) {
-            const int y = y0 + j;
-            o[j] = Mc[(size_t)min(y + m, H - 1) * W] - Mc[(size_t)min(max(y - m - 1, 0), H - 1) * W];
-        }
-    };
-    fetch(0, d);
-    for (int y0 = 0; y0 < H; y0 += LAT_U) {
-        if (y0 + LAT_U < H) fetch(y0 + LAT_U, nd);
+            for (int j = 0; j < LC_R; j++) {
+                a[j] = Mat(y0 + j + m);
+                b[j] = Mat(y0 + j - m - 1);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < LAT_U; j++) {
-            if (y0 + j < H) {
-                vs += (double)d[j];
-                Vc[(size_t)(y0 + j) * vrow] = vs;
+            for (int j = 0; j < LC_R; j++) {
+                a[j] = Mat(min(y0 + j + m, H - 1));
+                b[j] = Mat(min(max(y0 + j - m - 1, 0), H - 1));
             }
         }
-#pragma unroll
-        for (int j = 0; j < LAT_U; j++) d[j] = nd[j];
+    };
+    fetch(wave * LC_R);
+    if (wave == 0) {
+        double vs = (double)(Mat(0) * (float)(m + 2));
+        for (int y = 1; y < m; y++) vs += (double)Mat(min(y, H - 1));
+        carry[lane] = vs;
     }
+    for (int p0 = 0; p0 < H; p0 += LC_PASS) {
+        for (int k = 0; k < LC_WAVES; k++) {
+            const int y0 = p0 + k * LC_R;
+            if (y0 >= H) break;                               // uniform over the workgroup
+            __syncthreads();                                  // the running sums up to row y0 - 1 are in LDS
+            if (wave == k) {
+                if (live) {
+                    double vs = carry[lane];
+                    unsigned off = (unsigned)y0 * vrow + xv;
+                    if (y0 + LC_R <= H) {
+#pragma unroll
+                        for (int j = 0; j < LC_R; j++) {
+                            vs += (double)(a[j] - b[j]);      // the difference is rounded to float before it is added
+                            *reinterpret_cast<double*>(vb + off) = vs;
+                            off += vrow;
+                        }
+                    } else {
+                        for (int j = 0; j < H - y0; j++) {    // last, partial block (a[], b[] indexed dynamically: rare, short)
+                            float d = 0.f;
+#pragma unroll
+                            for (int q = 0; q < LC_R; q++) d = q == j ? a[q] - b[q] : d;
+                            vs += (double)d;
+                            *reinterpret_cast<double*>(vb + off) = vs;
+                            off += vrow;
+                        }
+                    }
+                    carry[lane] = vs;
+                }
+                if (y0 + LC_PASS < H) fetch(y0 + LC_PASS);
+            }
+        }
+    }
+}
+
+// The library's running row sums + the 2x2 solve, pipelined inside a workgroup that owns LR_ROWS image rows:
+//   chain waves   thread <-> (plane, row): per 16-column tile, the tile's window of column sums from an LDS ring (static
+//                 offsets: the ring repeats its first 32 columns behind the 64th, and the replicated borders are stored
+//                 as columns), 16 steps of S += V[x + m] - V[x - m - 1], S -> LDS
+//   solver waves  thread <-> pixel of the PREVIOUS tile: the 2x2 solve and the flow store
+//   loader waves  keep the ring fed, 8 chunks of 16 columns in flight in registers (coalesced 128-B row segments of V)
+// One barrier per tile.  Arithmetic and order as k_rowscan_solve / the library, bit for bit.
+#ifndef NSOF_LR_ROWS
+#define NSOF_LR_ROWS 8
+#endif
+constexpr int LR_ROWS = NSOF_LR_ROWS, LR_TW = 16, LR_SLOTS = 96, LR_SSTR = LR_ROWS + 1, LR_PLANE = LR_SLOTS * LR_SSTR + 8;
+static_assert(LR_ROWS == 4 || LR_ROWS == 8 || LR_ROWS == 16, "rows per workgroup");
+constexpr int LR_JSTR = LR_ROWS + 4, LR_SPLANE = LR_TW * LR_JSTR + 8, LR_DEPTH = 8;
+constexpr int LR_CHAIN = (5 * LR_ROWS + 63) / 64 * 64, LR_SOLVE = LR_TW * LR_ROWS, LR_LOAD = LR_SOLVE;
+constexpr int LR_THREADS = LR_CHAIN + LR_SOLVE + LR_LOAD;
+constexpr size_t LR_SMEM = sizeof(double) * (5 * LR_PLANE + 2 * 5 * LR_SPLANE);
+
+template <int MH, bool HET>
+__global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __restrict__ V, int W, int H, int block_size,
+                                                            float* __restrict__ flow, const nsof_het_item* __restrict__ items,
+                                                            int het_final)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_lr[];
+    double* ring = reinterpret_cast<double*>(smem_lr);                       // [5][LR_SLOTS][LR_SSTR] (+8 per plane)
+    double* St = ring + 5 * LR_PLANE;                                        // [2][5][LR_TW][LR_JSTR] (+8 per plane)
+    const int tid = threadIdx.x;
+    size_t fpitch;
+    float2* Fout;
+    if constexpr (HET) {
+        const nsof_het_item& it = items[blockIdx.z];
+        W = it.wk;
+        H = it.hk;
+        if (blockIdx.x * LR_ROWS >= H) return;   // block-uniform, before any barrier
+        V += it.offR / 2;
+        if (het_final) {
+            Fout = reinterpret_cast<float2*>(it.out);
+            fpitch = (size_t)it.out_pitch;
+        } else {
+            Fout = reinterpret_cast<float2*>(flow) + it.offF;
+            fpitch = (size_t)W;
+        }
+    } else {
+        V += (size_t)blockIdx.z * 5 * W * H;
+        Fout = reinterpret_cast<float2*>(flow) + (size_t)blockIdx.z * W * H;
+        fpitch = (size_t)W;
+    }
+    const int y0 = blockIdx.x * LR_ROWS;
+    const int T = (W + LR_TW - 1) / LR_TW;
+    const double scale = 1. / (block_size * block_size);
+    const int role = __builtin_amdgcn_readfirstlane(tid < LR_CHAIN ? 0 : tid < LR_CHAIN + LR_SOLVE ? 1 : 2);   // wave-uniform: chain, solver, loader
+    // loader role: thread <-> (column cx, row lr) of a chunk, its 5 planes in turn; chunk u = columns
+    // [16 u, 16 u + 16), replicated beyond the image.  Wave-uniform base + 32-bit byte offsets (40 W H < 4 GB, checked by
+    // the driver).
+    const int li = (tid - LR_CHAIN) & (LR_SOLVE - 1);   // index within the solver / the loader group
+    const int cx = li & 15, lr = (li >> 4) & (LR_ROWS - 1);
+    const char* vb = reinterpret_cast<const char*>(V);
+    const unsigned vrow0 = (unsigned)min(y0 + lr, H - 1) * 5u * (unsigned)W;
+    auto chunk_src = [&](int u, int k) {
+        const unsigned xcl = (unsigned)min(max(u * LR_TW + cx, 0), W - 1);
+        return *reinterpret_cast<const double*>(vb + (vrow0 + (unsigned)k * (unsigned)W + xcl) * 8u);
+    };
+    auto chunk_put = [&](int u, int k, double v) {
+        double* q = ring + k * LR_PLANE + ((u * LR_TW + cx) & 63) * LR_SSTR + lr;
+        q[0] = v;
+        if (((u * LR_TW) & 63) < 32) q[64 * LR_SSTR] = v;   // uniform: the chunk lies in the repeated part of the ring
+    };
+    double regs[LR_DEPTH][5];
+    if (role == 2) {
+#pragma unroll
+        for (int u = -1; u <= 1; u++) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) chunk_put(u, k, chunk_src(u, k));
+        }
+#pragma unroll
+        for (int d = 0; d < LR_DEPTH; d++) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) regs[d][k] = chunk_src(2 + d, k);
+        }
+    }
+    __syncthreads();
+    // chain role: thread <-> (plane cc, row cr)
+    const int cc = min(tid / LR_ROWS, 4), cr = tid & (LR_ROWS - 1);
+    const bool chain_on = tid < 5 * LR_ROWS;
+    const double* rc = ring + cc * LR_PLANE + cr;
+    double S = 0.;
+    if (chain_on) {
+        S = rc[0] * (MH + 2);                                 // columns 0 .. m-1 of the image sit in slots 0 .. m-1
+#pragma unroll
+        for (int x = 1; x < MH; x++) S += rc[x * LR_SSTR];
+    }
+    // solver role: pixel (sj, sr) of the tile
+    const int sj = li & 15, sr = li >> 4;
+    auto step = [&](auto kc, int s) {
+        constexpr int K = decltype(kc)::value;
+        if (role == 0) {
+#if !(defined(NSOF_LR_ABL) && NSOF_LR_ABL == 2)   // timing-only build: no chain
+            if (chain_on) {
+                const int b0 = (s * LR_TW - 8) & 63;          // window columns [16 s - 8, 16 s + 22] at slots b0 .. b0 + 30
+                const double* wp = rc + b0 * LR_SSTR;
+                double w[31];
+#pragma unroll
+                for (int k = 7 - MH; k <= 23 + MH; k++) w[k] = wp[k * LR_SSTR];
+                double* so = St + (s & 1) * 5 * LR_SPLANE + cc * LR_SPLANE + cr;
+#pragma unroll
+                for (int j = 0; j < LR_TW; j++) {
+                    S += w[j + 8 + MH] - w[j + 7 - MH];
+                    so[j * LR_JSTR] = S;
+                }
+            }
+#endif
+        } else if (role == 2) {
+            // keep the ring fed: chunk s + 2 was requested LR_DEPTH steps ago; request chunk s + 2 + LR_DEPTH
+#if !(defined(NSOF_LR_ABL) && NSOF_LR_ABL == 3)   // timing-only build: no ring refill
+#if !(defined(NSOF_LR_ABL) && NSOF_LR_ABL == 4)   // timing-only build: loads without the LDS writes
+#pragma unroll
+            for (int k = 0; k < 5; k++) chunk_put(s + 2, k, regs[K][k]);
+#else
+            if (regs[K][0] == 1.2345e300) chunk_put(s + 2, 0, regs[K][1] + regs[K][2] + regs[K][3] + regs[K][4]);
+#endif
+#if defined(NSOF_LR_ABL) && NSOF_LR_ABL == 5      // timing-only build: LDS writes without the loads
+            if (s < 0) {
+#else
+            if (s + 2 + LR_DEPTH <= T + 1) {
+#endif
+#pragma unroll
+                for (int k = 0; k < 5; k++) regs[K][k] = chunk_src(s + 2 + LR_DEPTH, k);
+            }
+#endif
+        } else {
+#if defined(NSOF_LR_ABL) && NSOF_LR_ABL == 1      // timing-only build: no solve
+            if (s < 0) {
+#else
+            if (s > 0) {
+#endif
+                const int x = (s - 1) * LR_TW + sj, y = y0 + sr;
+                const double* sp = St + ((s - 1) & 1) * 5 * LR_SPLANE + sj * LR_JSTR + sr;
+                const double g11 = sp[0] * scale, g12 = sp[LR_SPLANE] * scale, g22 = sp[2 * LR_SPLANE] * scale;
+                const double h1 = sp[3 * LR_SPLANE] * scale, h2 = sp[4 * LR_SPLANE] * scale;
+                if (x < W && y < H) {
+                    const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
+                    Fout[(size_t)y * fpitch + x] =
+                        make_float2((float)((g11 * h2 - g12 * h1) * idet), (float)((g22 * h1 - g12 * h2) * idet));
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int s = 0; s <= T; s += LR_DEPTH) {   // step T only solves the last tile (its chain / ring work is harmless)
+        step(std::integral_constant<int, 0>{}, s);
+        if (s + 1 <= T) step(std::integral_constant<int, 1>{}, s + 1);
+        if (s + 2 <= T) step(std::integral_constant<int, 2>{}, s + 2);
+        if (s + 3 <= T) step(std::integral_constant<int, 3>{}, s + 3);
+        if (s + 4 <= T) step(std::integral_constant<int, 4>{}, s + 4);
+        if (s + 5 <= T) step(std::integral_constant<int, 5>{}, s + 5);
+        if (s + 6 <= T) step(std::integral_constant<int, 6>{}, s + 6);
+        if (s + 7 <= T) step(std::integral_constant<int, 7>{}, s + 7);
+    }
+    static_assert(LR_DEPTH == 8, "the step loop is unrolled by the prefetch depth");
+}
+
+template <int MH>
+int launch_lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const double* V, int winsize, float* flow_out,
+                       const nsof_het_item* items, bool final)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
+    if (items) {
+        if (int rc = lds_opt_in(ctx, k_lat_rowscan<MH, true>, LR_SMEM)) return rc;
+        hipLaunchKernelGGL((k_lat_rowscan<MH, true>), dim3((max_h + LR_ROWS - 1) / LR_ROWS, 1, n), dim3(LR_THREADS), LR_SMEM,
+                           ctx->stream, V, 0, 0, winsize, flow_out, items, final ? 1 : 0);
+    } else {
+        if (int rc = lds_opt_in(ctx, k_lat_rowscan<MH, false>, LR_SMEM)) return rc;
+        hipLaunchKernelGGL((k_lat_rowscan<MH, false>), dim3((H + LR_ROWS - 1) / LR_ROWS, 1, n), dim3(LR_THREADS), LR_SMEM,
+                           ctx->stream, V, W, H, winsize, flow_out, nullptr, 0);
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+int lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const double* V, int winsize, float* flow_out,
+                const nsof_het_item* items, bool final)
+{
+    static const bool old = getenv("NSOF_LAT_ROWSCAN_OLD") != nullptr;   // A/B: the two-kernel form's row scan
+    if (old)
+        return items ? nsof_launch_rowscan_solve_het(ctx, n, items, max_h, V, flow_out, final, winsize)
+                     : nsof_launch_rowscan_solve(ctx, n, V, W, H, winsize, flow_out);
+    switch (winsize / 2) {
+#define NSOF_LR(MM) case MM: return launch_lat_rowscan<MM>(ctx, n, W, H, max_h, V, winsize, flow_out, items, final)
+        NSOF_LR(1); NSOF_LR(2); NSOF_LR(3); NSOF_LR(4); NSOF_LR(5); NSOF_LR(6); NSOF_LR(7);
+#undef NSOF_LR
+    }
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "small-batch exact iteration supports winsize 2..15");
 }
 
 }  // namespace
@@ -107,10 +340,10 @@ int nsof_launch_iterate_lat(nsof_ctx* ctx, int n_pairs, const float* R0, const f
         nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
         hipLaunchKernelGGL(k_lat_matrices<false>, dim3((W + 63) / 64, (H + 3) / 4, n_pairs), dim3(256), 0, ctx->stream, R0, R1,
                            pair_stride, flow_in, W, H, M, nullptr);
-        hipLaunchKernelGGL(k_lat_colsum<false>, dim3((W + 63) / 64, 5, n_pairs), dim3(64), 0, ctx->stream, (const float*)M, W, H,
+        hipLaunchKernelGGL(k_lat_colsum<false>, dim3((W + 63) / 64, 5, n_pairs), dim3(64 * LC_WAVES), 0, ctx->stream, (const float*)M, W, H,
                            winsize / 2, V, nullptr);
     }
-    return nsof_launch_rowscan_solve(ctx, n_pairs, V, W, H, winsize, flow_out);
+    return lat_rowscan(ctx, n_pairs, W, H, H, V, winsize, flow_out, nullptr, false);
 }
 
 int nsof_launch_iterate_lat_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
@@ -120,8 +353,8 @@ int nsof_launch_iterate_lat_het(nsof_ctx* ctx, int n_items, const nsof_het_item*
         nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
         hipLaunchKernelGGL(k_lat_matrices<true>, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_items), dim3(256), 0, ctx->stream, R, R,
                            (size_t)0, flow_in, 0, 0, M, d_items);
-        hipLaunchKernelGGL(k_lat_colsum<true>, dim3((max_w + 63) / 64, 5, n_items), dim3(64), 0, ctx->stream, (const float*)M, 0, 0,
+        hipLaunchKernelGGL(k_lat_colsum<true>, dim3((max_w + 63) / 64, 5, n_items), dim3(64 * LC_WAVES), 0, ctx->stream, (const float*)M, 0, 0,
                            winsize / 2, V, d_items);
     }
-    return nsof_launch_rowscan_solve_het(ctx, n_items, d_items, max_h, V, flow_out, final, winsize);
+    return lat_rowscan(ctx, n_items, 0, 0, max_h, V, winsize, flow_out, d_items, final);
 }

@@ -597,7 +597,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
                          nsof_iterate_x_supported(winsize, width, height);
     // a batch too small to fill the chip with (strip, image) jobs takes the three-kernel small-batch form of the same
     // order (farneback_iterate_lat.hip; NSOF_OPT_SMALL_BATCH_JOBS)
-    const bool exact_lat = exact_x && (long long)n_pairs * ((width + 191) / 192) <= ctx->opt_small_batch_jobs;
+    const bool exact_lat = exact_x && (long long)n_pairs * ((width + 191) / 192) <= ctx->opt_small_batch_jobs &&
+                           (unsigned long long)width * height * 40ull < (1ull << 32);   // its kernels address a pair with 32-bit byte offsets
     static const int exact_chunk = [] {
         const char* e = getenv("NSOF_EXACT_CHUNK");
         const int v = e ? atoi(e) : 64;

@@ -27,7 +27,7 @@ struct nsof_ctx {
     int opt_polyexp_f32 = 0;   // NSOF_OPT_POLYEXP_F32
     int opt_exact_rowsums = 1; // NSOF_OPT_EXACT_ROWSUMS (default: the library's row-sum order)
     int opt_row_bands = 0;     // NSOF_OPT_ROW_BANDS: 0 off, 1 automatic, >= 4 rows per band
-    int opt_small_batch_jobs = 256;   // NSOF_OPT_SMALL_BATCH_JOBS: calls with at most this many (strip, image) jobs take the three-kernel exact form
+    int opt_small_batch_jobs = 64;    // NSOF_OPT_SMALL_BATCH_JOBS: calls with at most this many (strip, image) jobs take the three-kernel exact form
     int opt_pyr_fma = 0;       // NSOF_OPT_PYR_FMA: pyramid blur / resamples with fused multiply-adds (arithmetic variant twin)
     char err[512] = {0};
     // reusable device workspace of the Farneback driver

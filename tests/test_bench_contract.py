@@ -71,6 +71,7 @@ def test_bench_json_contract():
     assert sc["default"]["host_to_host_ms"] > 0 and sc["row_bands"]["device_resident_ms"] > 0
     assert sc["fast_rowsums"]["host_to_host_ms"] > 0
     assert sc["row_bands"]["max_abs_vs_default"] < 1e-3
+    assert sc["default_fused_kernel_only"]["max_abs_vs_default"] == 0.0 and sc["default_801x801_params_B"]["host_to_host_ms"] > 0
 
 
 @pytest.mark.gpu

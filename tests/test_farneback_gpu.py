@@ -623,7 +623,7 @@ def test_small_batch_form_is_bit_identical_to_fused_kernel(nsof_lib, ctx, oracle
     arithmetic, same order: both forms equal the oracle bit for bit, lone calls and ROI work lists, every window
     the fused kernel covers, ragged and tiny sizes included."""
     from nsof import _lib, synth
-    assert ctx.get_option(_lib.OPT_SMALL_BATCH_JOBS) == 256
+    assert ctx.get_option(_lib.OPT_SMALL_BATCH_JOBS) == 64
     cases = [((135, 240), A), ((200, 303), B), ((97, 131), Cc), ((33, 17), (0.5, 2, 5, 2, 5, 1.1, 0)),
              ((70, 450), (0.6, 3, 15, 2, 7, 1.5, 0)), ((257, 64), (0.5, 1, 2, 3, 5, 1.2, 0)), ((16, 16), (0.5, 0, 9, 1, 5, 1.1, 0)),
              ((540, 960), A)]
@@ -631,7 +631,7 @@ def test_small_batch_form_is_bit_identical_to_fused_kernel(nsof_lib, ctx, oracle
         for k, (shape, params) in enumerate(cases):
             prev, nxt = synth.make_pair(60 + k, *shape)
             want = oracle.farneback(prev, nxt, *params)
-            for jobs in (0, 256):
+            for jobs in (0, 1 << 30):
                 ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, jobs)
                 got = nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *params, ctx=ctx)
                 assert np.array_equal(got, want), (shape, params, jobs, float(np.abs(got - want).max()))
@@ -640,7 +640,7 @@ def test_small_batch_form_is_bit_identical_to_fused_kernel(nsof_lib, ctx, oracle
         rects = [(0, 0, 600, 400), (10, 20, 210, 140), (301, 7, 364, 390), (100, 100, 133, 121), (17, 250, 590, 399)]
         pairs = [(big_p[y0:y1, x0:x1], big_n[y0:y1, x0:x1]) for (x0, y0, x1, y1) in rects]
         ref = [oracle.farneback(np.ascontiguousarray(a), np.ascontiguousarray(b), *B) for a, b in pairs]
-        for jobs in (0, 256):
+        for jobs in (0, 1 << 30):
             ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, jobs)
             flows = nsof_lib.farneback_pairs(pairs, nsof_lib.farneback.PARAMS_B, ctx=ctx)
             for f, r in zip(flows, ref):
@@ -648,4 +648,4 @@ def test_small_batch_form_is_bit_identical_to_fused_kernel(nsof_lib, ctx, oracle
         with pytest.raises(nsof_lib.NsofError):
             ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, -1)
     finally:
-        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 256)
+        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 64)
