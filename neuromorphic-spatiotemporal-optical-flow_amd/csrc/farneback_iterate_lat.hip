@@ -11,6 +11,9 @@
 // Same arithmetic, same order, same bits as k_iterate_x (upstream FarnebackUpdateFlow_Blur, optflowgf.cpp); 60 B/px of extra HBM traffic, which is why large batches keep the fused kernel.
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
+#include <utility>
+
 #include "iterate_common.h"
 
 namespace {
@@ -52,20 +55,23 @@ __global__ __launch_bounds__(256) void k_lat_matrices(const float* __restrict__ 
 // The library's column sums (FarnebackUpdateFlow_Blur's vsum rows): vsum = float(M[0] * (m + 2)), += M[y] for y = 1..m-1,
 // then per row += double(float(M[y + m] - M[y - m - 1])) with replicated borders.  One double addition per row is the
 // whole recurrence (~10 clocks); what a lone wave cannot do is keep enough rows in flight -- a wave may have 64 memory
-// operations outstanding (vmcnt), ~20 rows against ~2000 clocks of latency.  So the 16 waves of a workgroup take turns:
-// wave k owns rows [24 k, 24 k + 24) of every 384-row pass, has their loads in flight long before its turn, adds them to
-// the running sums handed over through LDS, and requests its rows of the next pass.
-constexpr int LC_WAVES = 16, LC_R = 24, LC_PASS = LC_WAVES * LC_R;
+// operations outstanding (vmcnt), ~20 rows against ~2000 clocks of latency -- nor issue the loads, float differences,
+// conversions and stores of a row in the time of one addition.  So the 8 waves of a workgroup take turns: wave k owns
+// rows [32 k, 32 k + 32) of every 256-row pass; long before its turn it has loaded them and formed the 32 addends, in its
+// turn it only runs the 32 additions on the running sums handed over through LDS and passes them on (a turn counter in
+// LDS, no workgroup barrier: the next wave starts while this one stores its rows and requests its next ones).
+constexpr int LC_WAVES = 8, LC_R = 32, LC_PASS = LC_WAVES * LC_R;
 template <bool HET>
 __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __restrict__ M, int W, int H, int m,
                                                                double* __restrict__ V, const nsof_het_item* __restrict__ items)
 {
     __shared__ double carry[64];
+    __shared__ int turns_done;
     if constexpr (HET) {
         const nsof_het_item& it = items[blockIdx.z];
         W = it.wk;
         H = it.hk;
-        if (blockIdx.x * 64 >= W) return;   // block-uniform, before any barrier
+        if (blockIdx.x * 64 >= W) return;   // block-uniform, before the barrier
         M += it.offR / 2;
         V += it.offR / 2;
     } else {
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = blockIdx.x * 64 + lane, c = blockIdx.y;
     const bool live = x < W;                                  // lanes beyond the image load a clamped column and store nothing
-    // wave-uniform bases + 32-bit byte offsets (the launcher checks 40 W H < 4 GB): one VALU add per address
+    // wave-uniform bases + 32-bit byte offsets (the driver checks 40 W H < 4 GB): one VALU add per address
     const char* mb = reinterpret_cast<const char*>(M + (size_t)c * W * H);
     char* vb = reinterpret_cast<char*>(V + (size_t)c * W);   // V[(y * 5 + c) * W + x]
     const unsigned xm = 4u * (unsigned)min(x, W - 1), xv = 8u * (unsigned)x;
@@ -102,36 +108,47 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
         double vs = (double)(Mat(0) * (float)(m + 2));
         for (int y = 1; y < m; y++) vs += (double)Mat(min(y, H - 1));
         carry[lane] = vs;
+        if (lane == 0) turns_done = 0;
     }
-    for (int p0 = 0; p0 < H; p0 += LC_PASS) {
-        for (int k = 0; k < LC_WAVES; k++) {
-            const int y0 = p0 + k * LC_R;
-            if (y0 >= H) break;                               // uniform over the workgroup
-            __syncthreads();                                  // the running sums up to row y0 - 1 are in LDS
-            if (wave == k) {
-                if (live) {
-                    double vs = carry[lane];
-                    unsigned off = (unsigned)y0 * vrow + xv;
-                    if (y0 + LC_R <= H) {
+    __syncthreads();
+    for (int p = 0;; p++) {
+        const int y0 = p * LC_PASS + wave * LC_R;
+        if (y0 >= H) break;
+        double dd[LC_R];
 #pragma unroll
-                        for (int j = 0; j < LC_R; j++) {
-                            vs += (double)(a[j] - b[j]);      // the difference is rounded to float before it is added
-                            *reinterpret_cast<double*>(vb + off) = vs;
-                            off += vrow;
-                        }
-                    } else {
-                        for (int j = 0; j < H - y0; j++) {    // last, partial block (a[], b[] indexed dynamically: rare, short)
-                            float d = 0.f;
+        for (int j = 0; j < LC_R; j++) dd[j] = (double)(a[j] - b[j]);   // the difference is rounded to float before it is added
+        if (y0 + LC_PASS < H) fetch(y0 + LC_PASS);                     // this wave's rows of the next pass: in flight early
+        // wait for this wave's turn (every earlier turn belongs to a resident wave of this workgroup; bounded all the same)
+        const int my = p * LC_WAVES + wave;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&turns_done)) == my) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        double vs = *reinterpret_cast<volatile double*>(&carry[lane]);
+        const int n = min(LC_R, H - y0);
+        if (n == LC_R) {
 #pragma unroll
-                            for (int q = 0; q < LC_R; q++) d = q == j ? a[q] - b[q] : d;
-                            vs += (double)d;
-                            *reinterpret_cast<double*>(vb + off) = vs;
-                            off += vrow;
-                        }
-                    }
-                    carry[lane] = vs;
-                }
-                if (y0 + LC_PASS < H) fetch(y0 + LC_PASS);
+            for (int j = 0; j < LC_R; j++) {
+                vs += dd[j];
+                dd[j] = vs;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LC_R; j++) {
+                if (j < n) vs += dd[j];
+                dd[j] = vs;
+            }
+        }
+        *reinterpret_cast<volatile double*>(&carry[lane]) = vs;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the sums are in LDS before the counter moves
+        if (lane == 0) *reinterpret_cast<volatile int*>(&turns_done) = my + 1;
+        if (live) {
+            unsigned off = (unsigned)y0 * vrow + xv;
+#pragma unroll
+            for (int j = 0; j < LC_R; j++) {
+                if (j < n) *reinterpret_cast<double*>(vb + off) = dd[j];
+                off += vrow;
             }
         }
     }
@@ -145,14 +162,29 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
 //   loader waves  keep the ring fed, 8 chunks of 16 columns in flight in registers (coalesced 128-B row segments of V)
 // One barrier per tile.  Arithmetic and order as k_rowscan_solve / the library, bit for bit.
 #ifndef NSOF_LR_ROWS
-#define NSOF_LR_ROWS 8
+#define NSOF_LR_ROWS 4
 #endif
-constexpr int LR_ROWS = NSOF_LR_ROWS, LR_TW = 16, LR_SLOTS = 96, LR_SSTR = LR_ROWS + 1, LR_PLANE = LR_SLOTS * LR_SSTR + 8;
+#ifndef NSOF_LR_TW
+#define NSOF_LR_TW 32
+#endif
+constexpr int LR_ROWS = NSOF_LR_ROWS, LR_TW = NSOF_LR_TW, LR_RING = 4 * LR_TW, LR_SLOTS = 6 * LR_TW, LR_SSTR = LR_ROWS + 1;
+constexpr int LR_PLANE = LR_SLOTS * LR_SSTR + 8;
+static_assert(LR_TW == 16 || LR_TW == 32, "tile width");
 static_assert(LR_ROWS == 4 || LR_ROWS == 8 || LR_ROWS == 16, "rows per workgroup");
-constexpr int LR_JSTR = LR_ROWS + 4, LR_SPLANE = LR_TW * LR_JSTR + 8, LR_DEPTH = 8;
+constexpr int LR_JSTR = LR_TW == 16 ? LR_ROWS + 4 : LR_ROWS + 1, LR_SPLANE = LR_TW * LR_JSTR + 8;
+#ifndef NSOF_LR_DEPTH
+#define NSOF_LR_DEPTH 4
+#endif
+constexpr int LR_DEPTH = NSOF_LR_DEPTH;
 constexpr int LR_CHAIN = (5 * LR_ROWS + 63) / 64 * 64, LR_SOLVE = LR_TW * LR_ROWS, LR_LOAD = LR_SOLVE;
 constexpr int LR_THREADS = LR_CHAIN + LR_SOLVE + LR_LOAD;
 constexpr size_t LR_SMEM = sizeof(double) * (5 * LR_PLANE + 2 * 5 * LR_SPLANE);
+
+template <class F, int... Ks>
+__device__ __forceinline__ void lr_steps(F& step, int s, int T, std::integer_sequence<int, Ks...>)
+{
+    (void)std::initializer_list<int>{(s + Ks <= T ? (step(std::integral_constant<int, Ks>{}, s + Ks), 0) : 0)...};
+}
 
 template <int MH, bool HET>
 __global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __restrict__ V, int W, int H, int block_size,
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __rest
     // [16 u, 16 u + 16), replicated beyond the image.  Wave-uniform base + 32-bit byte offsets (40 W H < 4 GB, checked by
     // the driver).
     const int li = (tid - LR_CHAIN) & (LR_SOLVE - 1);   // index within the solver / the loader group
-    const int cx = li & 15, lr = (li >> 4) & (LR_ROWS - 1);
+    const int cx = li & (LR_TW - 1), lr = (li / LR_TW) & (LR_ROWS - 1);
     const char* vb = reinterpret_cast<const char*>(V);
     const unsigned vrow0 = (unsigned)min(y0 + lr, H - 1) * 5u * (unsigned)W;
     auto chunk_src = [&](int u, int k) {
@@ -199,9 +231,9 @@ __global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __rest
         return *reinterpret_cast<const double*>(vb + (vrow0 + (unsigned)k * (unsigned)W + xcl) * 8u);
     };
     auto chunk_put = [&](int u, int k, double v) {
-        double* q = ring + k * LR_PLANE + ((u * LR_TW + cx) & 63) * LR_SSTR + lr;
+        double* q = ring + k * LR_PLANE + ((u * LR_TW + cx) & (LR_RING - 1)) * LR_SSTR + lr;
         q[0] = v;
-        if (((u * LR_TW) & 63) < 32) q[64 * LR_SSTR] = v;   // uniform: the chunk lies in the repeated part of the ring
+        if (((u * LR_TW) & (LR_RING - 1)) < 2 * LR_TW) q[LR_RING * LR_SSTR] = v;   // uniform: the chunk lies in the repeated part of the ring
     };
     double regs[LR_DEPTH][5];
     if (role == 2) {
@@ -228,17 +260,17 @@ __global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __rest
         for (int x = 1; x < MH; x++) S += rc[x * LR_SSTR];
     }
     // solver role: pixel (sj, sr) of the tile
-    const int sj = li & 15, sr = li >> 4;
+    const int sj = li & (LR_TW - 1), sr = li / LR_TW;
     auto step = [&](auto kc, int s) {
         constexpr int K = decltype(kc)::value;
         if (role == 0) {
 #if !(defined(NSOF_LR_ABL) && NSOF_LR_ABL == 2)   // timing-only build: no chain
             if (chain_on) {
-                const int b0 = (s * LR_TW - 8) & 63;          // window columns [16 s - 8, 16 s + 22] at slots b0 .. b0 + 30
+                const int b0 = (s * LR_TW - 8) & (LR_RING - 1);   // window columns [TW s - 8, TW s + TW + 6] at slots b0 .. b0 + TW + 14
                 const double* wp = rc + b0 * LR_SSTR;
-                double w[31];
+                double w[LR_TW + 15];
 #pragma unroll
-                for (int k = 7 - MH; k <= 23 + MH; k++) w[k] = wp[k * LR_SSTR];
+                for (int k = 7 - MH; k <= LR_TW + 7 + MH; k++) w[k] = wp[k * LR_SSTR];
                 double* so = St + (s & 1) * 5 * LR_SPLANE + cc * LR_SPLANE + cr;
 #pragma unroll
                 for (int j = 0; j < LR_TW; j++) {
@@ -284,17 +316,8 @@ __global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __rest
         }
         __syncthreads();
     };
-    for (int s = 0; s <= T; s += LR_DEPTH) {   // step T only solves the last tile (its chain / ring work is harmless)
-        step(std::integral_constant<int, 0>{}, s);
-        if (s + 1 <= T) step(std::integral_constant<int, 1>{}, s + 1);
-        if (s + 2 <= T) step(std::integral_constant<int, 2>{}, s + 2);
-        if (s + 3 <= T) step(std::integral_constant<int, 3>{}, s + 3);
-        if (s + 4 <= T) step(std::integral_constant<int, 4>{}, s + 4);
-        if (s + 5 <= T) step(std::integral_constant<int, 5>{}, s + 5);
-        if (s + 6 <= T) step(std::integral_constant<int, 6>{}, s + 6);
-        if (s + 7 <= T) step(std::integral_constant<int, 7>{}, s + 7);
-    }
-    static_assert(LR_DEPTH == 8, "the step loop is unrolled by the prefetch depth");
+    // step T only solves the last tile (its chain / ring work is harmless); unrolled by the prefetch depth (register sets)
+    for (int s = 0; s <= T; s += LR_DEPTH) lr_steps(step, s, T, std::make_integer_sequence<int, LR_DEPTH>{});
 }
 
 template <int MH>
