@@ -159,6 +159,20 @@ int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pa
 int nsof_farneback_u8_batch_desc_dev(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs,
                                      double pyr_scale, int levels, int winsize, int iterations,
                                      int poly_n, double poly_sigma, int flags);
+/* The gated path of a whole frame sequence on the device (opticalFlow3D's crop -> flow -> paste loop,
+ * /root/reference/optical_flow_seg.py:129-164, 186-204): d_frames = n_frames 8-bit frames in HBM, d_counts / d_rects = the
+ * ROI table nsof_roi_from_surface_dev wrote (rects [n_frames][max_rects][4] = x0, y0, x1, y1), d_flows =
+ * [n_frames - 1][height][width][2] float canvases, zero-filled here.  Pair k = (frame k, frame k + 1) is gated by the
+ * rectangles of frame k + 1; every crop of every pair is one item of ONE work list, written into the canvas in place;
+ * a crop that overlaps an earlier crop of its pair is pasted after it, in label order, as the reference's loop
+ * overwrites.  Each crop's flow equals nsof_farneback_u8 of that crop bit for bit.  Only the rectangle table crosses
+ * PCIe (the work list's shapes are needed on the host; the call synchronises the stream once for it).  n_calls /
+ * n_pixels (optional) receive the number of crops and their total area.  Asynchronous otherwise. */
+int nsof_farneback_u8_roi_sequence_dev(nsof_ctx* ctx, int n_frames, const uint8_t* d_frames, ptrdiff_t row_stride,
+                                       ptrdiff_t frame_stride, int width, int height, const int32_t* d_counts,
+                                       const int32_t* d_rects, int max_rects, float* d_flows, double pyr_scale, int levels,
+                                       int winsize, int iterations, int poly_n, double poly_sigma, int flags,
+                                       long long* n_calls, long long* n_pixels);
 /* Page-locked host memory for frames / flow fields handed to nsof_farneback_u8_batch (NULL on failure). */
 void* nsof_host_alloc(size_t bytes);
 void nsof_host_free(void* p);

@@ -393,6 +393,91 @@ extern "C" int nsof_farneback_u8_batch_desc_dev(nsof_ctx* ctx, int n_pairs, cons
     return het_core(ctx, n_pairs, pairs, p);
 }
 
+// Gated sequence on the device: frames [n_frames][height] rows of row_stride bytes, the ROI table of the gating kernel
+// (nsof_roi_from_surface_dev: counts [n_frames], rects [n_frames][max_rects][4] = x0, y0, x1, y1), flow canvases
+// [n_frames - 1][height][width][2].  Pair k = (frame k, frame k + 1) is gated by the rectangles of frame k + 1
+// (optical_flow_seg.py:129-164, 186-204); every crop of every pair becomes one work item, results land in the zeroed
+// canvases in place; a crop that overlaps an earlier crop of its pair (FLAG 1, extended component boxes) is computed into
+// a private buffer and pasted afterwards, in label order, as the reference's loop overwrites.  The only traffic over
+// PCIe is the rectangle table (16 bytes per ROI): the work list's shapes are needed on the host.
+extern "C" int nsof_farneback_u8_roi_sequence_dev(nsof_ctx* ctx, int n_frames, const uint8_t* d_frames, ptrdiff_t row_stride,
+                                                  ptrdiff_t frame_stride, int width, int height, const int32_t* d_counts,
+                                                  const int32_t* d_rects, int max_rects, float* d_flows, double pyr_scale,
+                                                  int levels, int winsize, int iterations, int poly_n, double poly_sigma,
+                                                  int flags, long long* n_calls, long long* n_pixels)
+{
+    if (!ctx) return NSOF_EINVAL;
+    if (!d_frames || !d_counts || !d_rects || !d_flows || n_frames < 2 || max_rects < 1 || width < 1 || height < 1 ||
+        row_stride < width)
+        return nsof_set_error(ctx, NSOF_EINVAL, "roi_sequence: bad argument");
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t canvas = (size_t)width * height * 2;   // floats per pair
+    NSOF_HIP(ctx, hipMemsetAsync(d_flows, 0, (size_t)(n_frames - 1) * canvas * 4, ctx->stream));
+    std::vector<int32_t> counts(n_frames), rects((size_t)n_frames * max_rects * 4);
+    NSOF_HIP(ctx, hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipMemcpyAsync(rects.data(), d_rects, rects.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    struct Paste { float* dst; size_t tmp_off; int w, h; };
+    std::vector<nsof_pair_desc> descs;
+    std::vector<Paste> pastes;
+    std::vector<size_t> tmp_slot;            // index into descs of the items whose flow pointer is a roi_tmp offset
+    size_t tmp_floats = 0;
+    long long pixels = 0;
+    for (int k = 0; k + 1 < n_frames; k++) {
+        const int cnt = counts[k + 1];
+        if (cnt < 0 || cnt > max_rects)
+            return nsof_set_error(ctx, NSOF_EINVAL, "roi_sequence: frame %d has %d rectangles, the table holds %d", k + 1, cnt, max_rects);
+        const int32_t* r = rects.data() + (size_t)(k + 1) * max_rects * 4;
+        for (int i = 0; i < cnt; i++) {
+            const int x0 = r[4 * i], y0 = r[4 * i + 1], x1 = r[4 * i + 2], y1 = r[4 * i + 3];
+            if (x1 <= x0 || y1 <= y0) continue;
+            if (x0 < 0 || y0 < 0 || x1 > width || y1 > height)
+                return nsof_set_error(ctx, NSOF_EINVAL, "roi_sequence: rectangle (%d,%d,%d,%d) leaves the %dx%d frame", x0, y0, x1, y1, width, height);
+            bool overlap = false;
+            for (int j = 0; j < i && !overlap; j++) {
+                const int a0 = r[4 * j], b0 = r[4 * j + 1], a1 = r[4 * j + 2], b1 = r[4 * j + 3];
+                overlap = a1 > a0 && b1 > b0 && x0 < a1 && a0 < x1 && y0 < b1 && b0 < y1;
+            }
+            nsof_pair_desc d;
+            d.prev = d_frames + (size_t)k * frame_stride + (size_t)y0 * row_stride + x0;
+            d.next = d_frames + (size_t)(k + 1) * frame_stride + (size_t)y0 * row_stride + x0;
+            d.prev_stride = d.next_stride = row_stride;
+            d.width = x1 - x0;
+            d.height = y1 - y0;
+            float* inplace = d_flows + (size_t)k * canvas + ((size_t)y0 * width + x0) * 2;
+            if (overlap) {
+                tmp_slot.push_back(descs.size());
+                pastes.push_back({inplace, tmp_floats, d.width, d.height});
+                d.flow = reinterpret_cast<float*>(tmp_floats * 4);     // offset for now: the buffer may still move
+                d.flow_stride = (ptrdiff_t)d.width * 8;
+                tmp_floats += (size_t)d.width * d.height * 2;
+            } else {
+                d.flow = inplace;
+                d.flow_stride = (ptrdiff_t)width * 8;
+            }
+            pixels += (long long)d.width * d.height;
+            descs.push_back(d);
+        }
+    }
+    if (n_calls) *n_calls = (long long)descs.size();
+    if (n_pixels) *n_pixels = pixels;
+    if (descs.empty()) return NSOF_OK;
+    if (tmp_floats) {
+        if (int rc = nsof_ws_reserve(ctx, &ctx->roi_tmp, &ctx->roi_tmp_bytes, tmp_floats * 4)) return rc;
+        for (size_t i : tmp_slot)
+            descs[i].flow = reinterpret_cast<float*>((char*)ctx->roi_tmp + reinterpret_cast<uintptr_t>(descs[i].flow));
+    }
+    const Params p{pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags};
+    for (size_t i = 0; i < descs.size(); i += 32767) {
+        const int n = (int)std::min<size_t>(32767, descs.size() - i);
+        if (int rc = het_core(ctx, n, descs.data() + i, p)) return rc;
+    }
+    for (const Paste& q : pastes)
+        NSOF_HIP(ctx, hipMemcpy2DAsync(q.dst, (size_t)width * 8, (const char*)ctx->roi_tmp + q.tmp_off * 4, (size_t)q.w * 8,
+                                       (size_t)q.w * 8, (size_t)q.h, hipMemcpyDeviceToDevice, ctx->stream));
+    return NSOF_OK;
+}
+
 extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pair_desc* pairs, double pyr_scale,
                                        int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags)
 {

@@ -247,6 +247,7 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     if (ctx->het_h) hipHostFree(ctx->het_h);
     if (ctx->het_d) hipFree(ctx->het_d);
     if (ctx->x_carry) hipFree(ctx->x_carry);
+    if (ctx->roi_tmp) hipFree(ctx->roi_tmp);
     if (ctx->x_sync) hipFree(ctx->x_sync);
     for (auto ev : ctx->het_ev)
         if (ev) hipEventDestroy(ev);

@@ -58,6 +58,9 @@ struct nsof_ctx {
     // exact-order fused iteration (farneback_iterate_x.hip): strip-to-strip carries (tagged granules, zeroed when
     // allocated, never again: a launch's tag is its epoch), the per-XCD ticket counters + timeout word (x_sync:
     // tickets at word 0, timeout word at word 256), the launch epoch, and whether a launch's timeout word needs a look
+    // private flow buffers of ROI crops that overlap an earlier crop of the same frame pair (nsof_farneback_u8_roi_sequence_dev)
+    void* roi_tmp = nullptr;
+    size_t roi_tmp_bytes = 0;
     unsigned long long* x_carry = nullptr;
     size_t x_carry_bytes = 0;
     unsigned* x_sync = nullptr;

@@ -245,6 +245,28 @@ def farneback_pairs_dev(pairs, flows, params, *, ctx=None):
     ctx.check(rc, "farneback_pairs_dev")
 
 
+def farneback_roi_sequence_dev(frames, counts, rects, flows, params, *, ctx=None):
+    """The gated path of a frame sequence on the device (``nsof_farneback_u8_roi_sequence_dev``; opticalFlow3D's crop ->
+    flow -> paste loop, optical_flow_seg.py:129-164, 186-204): ``frames`` uint8 CUDA tensor [n][H][W] (row stride free),
+    ``counts`` / ``rects`` the device ROI table of ``gating.roi_from_surface_dev``, ``flows`` float32 CUDA tensor
+    [n-1][H][W][2] (contiguous; zero-filled by the call).  Pair k is gated by the rectangles of frame k+1; all crops of
+    all pairs form one work list; overlapping crops of a pair are pasted in label order.  -> (n_crops, crop_pixels)."""
+    ctx = ctx or default_context()
+    kw = params.as_kwargs() if hasattr(params, "as_kwargs") else dict(params)
+    n, h, w = (int(v) for v in frames.shape)
+    if tuple(flows.shape) != (n - 1, h, w, 2) or not flows.is_contiguous() or frames.stride(2) != 1:
+        raise NsofValueError("flows must be a contiguous (n-1, H, W, 2) tensor and the frames' pixel stride 1")
+    if tuple(rects.shape[:1]) != (n,) or rects.shape[2] != 4 or not rects.is_contiguous() or not counts.is_contiguous():
+        raise NsofValueError("rects must be a contiguous (n, max_rects, 4) int32 tensor")
+    calls, pixels = C.c_longlong(), C.c_longlong()
+    rc = ctx._lib.nsof_farneback_u8_roi_sequence_dev(
+        ctx.ptr, n, dev_ptr(frames), int(frames.stride(1)), int(frames.stride(0)), w, h, dev_ptr(counts), dev_ptr(rects),
+        int(rects.shape[1]), dev_ptr(flows), float(kw["pyr_scale"]), int(kw["levels"]), int(kw["winsize"]),
+        int(kw["iterations"]), int(kw["poly_n"]), float(kw["poly_sigma"]), int(kw["flags"]), C.byref(calls), C.byref(pixels))
+    ctx.check(rc, "farneback_roi_sequence_dev")
+    return calls.value, pixels.value
+
+
 def effective_levels(width, height, pyr_scale, levels):
     return _lib.load().nsof_farneback_effective_levels(width, height, pyr_scale, levels)
 

@@ -82,7 +82,7 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
     """BASELINE config 3 as one pipeline on the device: event stream -> leaky-integrate surface (scheme 1) -> every
     ``snapshot_every`` slices an 8-bit surface frame AND the gating map of the same state -> ROI rectangles on the device
     (``gating.roi_from_surface_dev``) -> Farneback flow of every ROI crop between consecutive surface frames, all crops of
-    all pairs as ONE work list (``farneback_pairs_dev``), written into frame-sized zero canvases exactly as
+    all pairs as ONE work list (``farneback_roi_sequence_dev``), written into frame-sized zero canvases exactly as
     ``opticalFlow3D`` pastes them (optical_flow_seg.py:129-164, 186-204: pair (k, k+1) is gated by the map of frame k+1;
     with FLAG 1 overlapping component boxes are pasted in label order, later ones winning).
     Events are uploaded once; frames, maps, rectangles and flow stay in HBM -- the only thing that crosses PCIe before the
@@ -94,7 +94,7 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
     import torch
 
     from .context import default_context
-    from .farneback import farneback_pairs_dev
+    from .farneback import farneback_roi_sequence_dev
     ctx = ctx or default_context()
     H, W = sensor_hw  # noqa: N806
     dev = torch.device("cuda", ctx.device)
@@ -105,7 +105,7 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
     rows, cols = H // cfg.MEMSIZE, W // cfg.MEMSIZE
     frames = torch.empty((n_frames, H, W), dtype=torch.uint8, device=dev)
     cur = torch.empty((n_frames, rows, cols), dtype=torch.float64, device=dev)
-    flows = torch.zeros((n_frames - 1, H, W, 2), dtype=torch.float32, device=dev)
+    flows = torch.empty((n_frames - 1, H, W, 2), dtype=torch.float32, device=dev)   # zero-filled by the flow call
     torch.cuda.synchronize(dev)
     acc = Accumulator(H, W, 1, "split", active_v, silent_v, ctx=ctx)
     try:
@@ -116,34 +116,17 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
             acc.surface_u8(frames[k], mode=surface_mode)
             acc.block_current_dev(cfg.MEMSIZE, cur[k])
         counts, rtab = gating.roi_from_surface_dev(cur, n_frames, (rows, cols), (H, W), cfg, max_rects=max_rects, ctx=ctx)
-        rects = gating.rects_to_host(counts, rtab, ctx=ctx)          # the one copy: 16 bytes per rectangle
-        t1 = time.perf_counter()
-        pairs, outs, pastes = [], [], []
-        for k in range(n_frames - 1):
-            seen = []
-            for (x0, y0, x1, y1) in rects[k + 1]:
-                if x1 <= x0 or y1 <= y0:
-                    continue
-                pairs.append((frames[k, y0:y1, x0:x1], frames[k + 1, y0:y1, x0:x1]))
-                view = flows[k, y0:y1, x0:x1]
-                if any(x0 < b[2] and b[0] < x1 and y0 < b[3] and b[1] < y1 for b in seen):
-                    tmp = torch.empty((y1 - y0, x1 - x0, 2), dtype=torch.float32, device=dev)   # overlaps an earlier box:
-                    outs.append(tmp)                                                             # pasted afterwards, in order
-                    pastes.append((view, tmp))
-                else:
-                    outs.append(view)
-                seen.append((x0, y0, x1, y1))
-        farneback_pairs_dev(pairs, outs, cfg.farneback_params, ctx=ctx)
         ctx.synchronize()
-        for view, tmp in pastes:
-            view.copy_(tmp)
-        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        # crop -> flow -> paste of every ROI of every pair: one native call builds the work list from the rectangle table
+        n_calls, n_pixels = farneback_roi_sequence_dev(frames, counts, rtab, flows, cfg.farneback_params, ctx=ctx)
+        ctx.synchronize()
         t2 = time.perf_counter()
+        rects = gating.rects_to_host(counts, rtab, ctx=ctx)
     finally:
         acc.close()
     if timings is not None:
-        timings.update(surface_and_gating_s=t1 - t0, flow_s=t2 - t1, frames=n_frames, roi_calls=len(pairs),
-                       roi_pixels=int(sum(a.shape[0] * a.shape[1] for a, _ in pairs)))
+        timings.update(surface_and_gating_s=t1 - t0, flow_s=t2 - t1, frames=n_frames, roi_calls=int(n_calls), roi_pixels=int(n_pixels))
     return frames, rects, flows
 
 
