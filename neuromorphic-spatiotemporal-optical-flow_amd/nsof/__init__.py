@@ -15,7 +15,8 @@ All arithmetic runs in libnsof.so (HIP, gfx950).  No fallbacks.
 from .errors import NsofError, error  # noqa: F401
 from .context import Context, default_context  # noqa: F401
 from .farneback import (FarnebackParams, StreamPool, calcOpticalFlowFarneback, effective_levels, farneback_batch,  # noqa: F401
-                        farneback_many, farneback_pairs, farneback_pairs_dev, farneback_sequence, install, level_size,
+                        farneback_many, farneback_pairs, farneback_pairs_dev, farneback_roi_sequence_dev,
+                        farneback_sequence, install, level_size,
                         pinned_empty, uninstall)
 from .accumulator import (PARAMS, DT, THETA_EVENTS, REFRACTORY_US, Accumulator, bincount_2d,  # noqa: F401
                           generate_synthetic_events, load_events, resistance_exp, simulate, simulate_frames,
