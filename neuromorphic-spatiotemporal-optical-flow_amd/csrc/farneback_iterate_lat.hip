@@ -154,31 +154,31 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
     }
 }
 
-// The library's running row sums + the 2x2 solve, pipelined inside a workgroup that owns LR_ROWS image rows:
-//   chain waves   thread <-> (plane, row): per 16-column tile, the tile's window of column sums from an LDS ring (static
-//                 offsets: the ring repeats its first 32 columns behind the 64th, and the replicated borders are stored
-//                 as columns), 16 steps of S += V[x + m] - V[x - m - 1], S -> LDS
+// The library's running row sums + the 2x2 solve, pipelined inside a workgroup that owns ROWS (4 or 8) image rows:
+//   chain wave    lane <-> (plane, row): per 32-column tile, the tile's window of column sums from an LDS ring (static
+//                 offsets: the ring repeats its first two chunks behind the fourth, and the replicated borders are stored
+//                 as columns), 32 steps of S += V[x + m] - V[x - m - 1], S -> LDS
 //   solver waves  thread <-> pixel of the PREVIOUS tile: the 2x2 solve and the flow store
-//   loader waves  keep the ring fed, 8 chunks of 16 columns in flight in registers (coalesced 128-B row segments of V)
-// One barrier per tile.  Arithmetic and order as k_rowscan_solve / the library, bit for bit.
-#ifndef NSOF_LR_ROWS
-#define NSOF_LR_ROWS 4
-#endif
+//   loader waves  keep the ring fed, 4 chunks of 32 columns in flight in registers (coalesced 256-B row segments of V)
+// One barrier per tile.  Arithmetic and order as k_rowscan_solve / the library, bit for bit.  Rows per workgroup: 4 while
+// that gives at most one workgroup per CU (the per-CU load rate is the limit: more, smaller workgroups win), else 8.
 #ifndef NSOF_LR_TW
 #define NSOF_LR_TW 32
 #endif
-constexpr int LR_ROWS = NSOF_LR_ROWS, LR_TW = NSOF_LR_TW, LR_RING = 4 * LR_TW, LR_SLOTS = 6 * LR_TW, LR_SSTR = LR_ROWS + 1;
-constexpr int LR_PLANE = LR_SLOTS * LR_SSTR + 8;
-static_assert(LR_TW == 16 || LR_TW == 32, "tile width");
-static_assert(LR_ROWS == 4 || LR_ROWS == 8 || LR_ROWS == 16, "rows per workgroup");
-constexpr int LR_JSTR = LR_TW == 16 ? LR_ROWS + 4 : LR_ROWS + 1, LR_SPLANE = LR_TW * LR_JSTR + 8;
 #ifndef NSOF_LR_DEPTH
 #define NSOF_LR_DEPTH 4
 #endif
-constexpr int LR_DEPTH = NSOF_LR_DEPTH;
-constexpr int LR_CHAIN = (5 * LR_ROWS + 63) / 64 * 64, LR_SOLVE = LR_TW * LR_ROWS, LR_LOAD = LR_SOLVE;
-constexpr int LR_THREADS = LR_CHAIN + LR_SOLVE + LR_LOAD;
-constexpr size_t LR_SMEM = sizeof(double) * (5 * LR_PLANE + 2 * 5 * LR_SPLANE);
+constexpr int LR_TW = NSOF_LR_TW, LR_RING = 4 * LR_TW, LR_SLOTS = 6 * LR_TW, LR_DEPTH = NSOF_LR_DEPTH;
+static_assert(LR_TW == 16 || LR_TW == 32, "tile width");
+template <int ROWS>
+struct LRGeom {
+    static_assert(ROWS == 4 || ROWS == 8 || ROWS == 16, "rows per workgroup");
+    static constexpr int SSTR = ROWS + 1, PLANE = LR_SLOTS * SSTR + 8;                       // ring: [5][LR_SLOTS][SSTR] (+8 per plane)
+    static constexpr int JSTR = LR_TW == 16 ? ROWS + 4 : ROWS + 1, SPLANE = LR_TW * JSTR + 8;   // S: [2][5][LR_TW][JSTR] (+8 per plane)
+    static constexpr int CHAIN = (5 * ROWS + 63) / 64 * 64, SOLVE = LR_TW * ROWS, LOAD = SOLVE;
+    static constexpr int THREADS = CHAIN + SOLVE + LOAD;
+    static constexpr size_t SMEM = sizeof(double) * (5 * PLANE + 2 * 5 * SPLANE);
+};
 
 template <class F, int... Ks>
 __device__ __forceinline__ void lr_steps(F& step, int s, int T, std::integer_sequence<int, Ks...>)
@@ -186,14 +186,17 @@ __device__ __forceinline__ void lr_steps(F& step, int s, int T, std::integer_seq
     (void)std::initializer_list<int>{(s + Ks <= T ? (step(std::integral_constant<int, Ks>{}, s + Ks), 0) : 0)...};
 }
 
-template <int MH, bool HET>
-__global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __restrict__ V, int W, int H, int block_size,
+template <int MH, bool HET, int LR_ROWS>
+__global__ __launch_bounds__(LRGeom<LR_ROWS>::THREADS) void k_lat_rowscan(const double* __restrict__ V, int W, int H, int block_size,
                                                             float* __restrict__ flow, const nsof_het_item* __restrict__ items,
                                                             int het_final)
 {
+    using G = LRGeom<LR_ROWS>;
+    constexpr int LR_SSTR = G::SSTR, LR_PLANE = G::PLANE, LR_JSTR = G::JSTR, LR_SPLANE = G::SPLANE, LR_CHAIN = G::CHAIN,
+                  LR_SOLVE = G::SOLVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_lr[];
-    double* ring = reinterpret_cast<double*>(smem_lr);                       // [5][LR_SLOTS][LR_SSTR] (+8 per plane)
-    double* St = ring + 5 * LR_PLANE;                                        // [2][5][LR_TW][LR_JSTR] (+8 per plane)
+    double* ring = reinterpret_cast<double*>(smem_lr);
+    double* St = ring + 5 * LR_PLANE;
     const int tid = threadIdx.x;
     size_t fpitch;
     float2* Fout;
@@ -320,18 +323,19 @@ __global__ __launch_bounds__(LR_THREADS) void k_lat_rowscan(const double* __rest
     for (int s = 0; s <= T; s += LR_DEPTH) lr_steps(step, s, T, std::make_integer_sequence<int, LR_DEPTH>{});
 }
 
-template <int MH>
+template <int MH, int ROWS>
 int launch_lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const double* V, int winsize, float* flow_out,
                        const nsof_het_item* items, bool final)
 {
+    using G = LRGeom<ROWS>;
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     if (items) {
-        if (int rc = lds_opt_in(ctx, k_lat_rowscan<MH, true>, LR_SMEM)) return rc;
-        hipLaunchKernelGGL((k_lat_rowscan<MH, true>), dim3((max_h + LR_ROWS - 1) / LR_ROWS, 1, n), dim3(LR_THREADS), LR_SMEM,
+        if (int rc = lds_opt_in(ctx, k_lat_rowscan<MH, true, ROWS>, G::SMEM)) return rc;
+        hipLaunchKernelGGL((k_lat_rowscan<MH, true, ROWS>), dim3((max_h + ROWS - 1) / ROWS, 1, n), dim3(G::THREADS), G::SMEM,
                            ctx->stream, V, 0, 0, winsize, flow_out, items, final ? 1 : 0);
     } else {
-        if (int rc = lds_opt_in(ctx, k_lat_rowscan<MH, false>, LR_SMEM)) return rc;
-        hipLaunchKernelGGL((k_lat_rowscan<MH, false>), dim3((H + LR_ROWS - 1) / LR_ROWS, 1, n), dim3(LR_THREADS), LR_SMEM,
+        if (int rc = lds_opt_in(ctx, k_lat_rowscan<MH, false, ROWS>, G::SMEM)) return rc;
+        hipLaunchKernelGGL((k_lat_rowscan<MH, false, ROWS>), dim3((H + ROWS - 1) / ROWS, 1, n), dim3(G::THREADS), G::SMEM,
                            ctx->stream, V, W, H, winsize, flow_out, nullptr, 0);
     }
     NSOF_HIP(ctx, hipGetLastError());
@@ -345,8 +349,13 @@ int lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const double* V, 
     if (old)
         return items ? nsof_launch_rowscan_solve_het(ctx, n, items, max_h, V, flow_out, final, winsize)
                      : nsof_launch_rowscan_solve(ctx, n, V, W, H, winsize, flow_out);
+    static const int rows_env = [] { const char* e = getenv("NSOF_LR_ROWS"); return e ? atoi(e) : 0; }();   // A/B: 4 or 8
+    const bool rows4 = rows_env ? rows_env == 4 : (long long)((max_h + 3) / 4) * n <= 256;
     switch (winsize / 2) {
-#define NSOF_LR(MM) case MM: return launch_lat_rowscan<MM>(ctx, n, W, H, max_h, V, winsize, flow_out, items, final)
+#define NSOF_LR(MM)                                                                                                  \
+    case MM:                                                                                                         \
+        return rows4 ? launch_lat_rowscan<MM, 4>(ctx, n, W, H, max_h, V, winsize, flow_out, items, final)            \
+                     : launch_lat_rowscan<MM, 8>(ctx, n, W, H, max_h, V, winsize, flow_out, items, final)
         NSOF_LR(1); NSOF_LR(2); NSOF_LR(3); NSOF_LR(4); NSOF_LR(5); NSOF_LR(6); NSOF_LR(7);
 #undef NSOF_LR
     }
