@@ -115,6 +115,8 @@ def main():
                     help="gather: after the headline run, an extra leg in which rank 0 owns every frame pair: frames go "
                          "to the ranks and flow comes back point to point over RCCL/xGMI, chunked and overlapped with "
                          "compute (nsof.dist.run_sharded_overlapped); printed as 'io_gather' next to the headline")
+    ap.add_argument("--io-timeout", type=float, default=240.0,
+                    help="seconds after which the scatter/compute/gather leg is abandoned (the headline line is printed regardless)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the joined events -> accumulator -> flow leg (BASELINE config 5) and its accumulator record")
     ap.add_argument("--no-fast-leg", action="store_true",
@@ -214,11 +216,10 @@ def main():
             prof[k] = ctx.prof_collect(k)
         ctx.prof_enable()
 
-    io_rec = None
-    if (args.io == "gather" or (args.io == "auto" and world > 1)) and args.mode == "pairs":
-        io_rec = io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w, prevs, nexts)
-
     exit_code = 0
+    out = None
+    wd = None
+    state = {"printed": False}
     if rank == 0:
         total_pairs = n * world * args.steps
         alg = algorithmic_bytes_per_pair(nsof, w, h, p)
@@ -251,8 +252,6 @@ def main():
         }
         if rehearsal:
             out["rehearsal"] = "NSOF_BENCH_REHEARSAL=1: ranks share the GPUs present, gloo collectives -- not a measurement"
-        if io_rec:
-            out["io_gather"] = io_rec
         if prof:
             dom = max(kernel_ids, key=lambda k: prof[k][0])
             out["roofline"] = roof(dom)
@@ -272,6 +271,30 @@ def main():
                                                       f"{ent['traffic_over_algorithmic']} from profiles/hbm_traffic.json "
                                                       "(rocprofv3 --pmc passes over this bench's own launches, all "
                                                       "levels: scripts/prof_traffic_bench.sh, see its _doc)")
+    # The scatter / compute / gather leg (every rank takes part).  The headline above is already measured: a watchdog makes
+    # sure it is printed even if this leg -- point-to-point RCCL traffic that a one-GPU box cannot rehearse -- hangs or
+    # fails on some rank (the line then carries the error instead of the leg's numbers).
+    if (args.io == "gather" or (args.io == "auto" and world > 1)) and args.mode == "pairs":
+        import threading
+
+        def emergency():
+            if rank == 0 and not state["printed"]:
+                out["io_gather"] = {"error": f"the scatter/compute/gather leg did not finish within {args.io_timeout} s"}
+                os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+
+        wd = threading.Timer(args.io_timeout, emergency)
+        wd.daemon = True
+        wd.start()
+        try:
+            io_rec = io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w, prevs, nexts)
+        except Exception as e:   # noqa: BLE001 -- reported in the line; peers stuck in a collective are ended by their watchdogs
+            io_rec = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if world == 1:
+            wd.cancel()           # N > 1: stays armed until the process group is torn down
+        if rank == 0 and io_rec:
+            out["io_gather"] = io_rec
+    if rank == 0:
         if world == 1 and prof and args.mode == "pairs" and not args.no_fast_leg:
             out.update(fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of=roof,
                                         prof=prof, steps=max(2, min(args.steps, 5))))
@@ -299,6 +322,7 @@ def main():
             if isinstance(out.get(key), dict) and out[key].get("parity_ok") is False:
                 out["parity_ok"] = False
         sys.stdout.flush()
+        state["printed"] = True
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if out.get("parity_ok") is False:
             print(f"bench: GPU flow differs from the CPU baseline by more than {out.get('epe_tolerance', 1e-4)} "
@@ -307,6 +331,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if wd is not None:
+        wd.cancel()
     ctx.close()
     if exit_code:
         sys.exit(exit_code)

@@ -91,3 +91,21 @@ def test_bench_two_rank_path_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["global_pairs_per_step"] == 16 and d["scaling"] == "weak"
     assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
     assert "rehearsal" in d and "cpu_baseline" not in d     # rank-0-only legs run at N = 1 only
+    io = d["io_gather"]
+    assert "error" not in io and io["value"] > 0 and io["world_size"] == 2 and io["backend"].startswith("gloo")
+
+
+@pytest.mark.gpu
+def test_bench_prints_the_headline_when_the_gather_leg_hangs():
+    """The N > 1 line must not depend on the scatter/compute/gather leg finishing: with a watchdog time of ~0 the leg is
+    abandoned on every rank, rank 0 still prints exactly one line carrying the measured headline and the error."""
+    env = dict(os.environ, NSOF_SKIP_BUILD="1", NSOF_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--pairs", "8", "--io-timeout", "0.01"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["io_gather"]["error"]
