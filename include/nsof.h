@@ -86,7 +86,7 @@ int nsof_synchronize(nsof_ctx* ctx);
  * pair (10 jobs at 1920 wide), a few ROI crops: the reference's own call pattern -- leaves most of the 256 compute
  * units idle, so such calls run the SAME arithmetic in the SAME order as three wide kernels per iteration (matrices;
  * column sums, one thread per column and plane; row sums + solve, one thread per row and plane) with the intermediates
- * in HBM: a lone 1920x1080 call 3.9 -> 1.4 ms host to host.  Results are bit-identical either way; the value only moves
+ * in HBM: a lone 1920x1080 call 3.9 -> 1.2 ms host to host.  Results are bit-identical either way; the value only moves
  * the switch-over (measured cross-over: 70-80 jobs, scripts/small_batch_crossover.py; 0 = always the fused kernel).
  * Environment default: NSOF_LAT_JOBS. */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3, NSOF_OPT_PYR_FMA = 4,
