@@ -649,3 +649,39 @@ def test_small_batch_form_is_bit_identical_to_fused_kernel(nsof_lib, ctx, oracle
             ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, -1)
     finally:
         ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 64)
+
+
+@pytest.mark.gpu
+def test_small_batch_form_edge_shapes_batches_and_sequences(nsof_lib, ctx, oracle, torch_dev):
+    """The three-kernel form on the shapes that stress its tiling (2x2, a 3-row strip, widths below one tile, odd sizes), on a
+    uniform device batch of several pairs and on a frame sequence: equal to the oracle / to the fused kernel bit for bit."""
+    import torch
+    from nsof import _lib, synth
+    try:
+        for (h, w) in [(2, 2), (3, 70), (5, 5), (9, 33), (64, 31), (130, 257)]:
+            big_a, big_b = synth.make_pair(11, max(h, 8), max(w, 8))
+            a, b = np.ascontiguousarray(big_a[:h, :w]), np.ascontiguousarray(big_b[:h, :w])
+            for params in [(0.5, 2, 3, 2, 5, 1.1, 0), (0.5, 1, 15, 1, 5, 1.2, 0), (0.7, 3, 6, 3, 7, 1.5, 0)]:
+                want = oracle.farneback(a, b, *params)
+                for jobs in (0, 1 << 30):
+                    ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, jobs)
+                    got = nsof_lib.calcOpticalFlowFarneback(a, b, None, *params, ctx=ctx)
+                    assert np.array_equal(got, want), (h, w, params, jobs)
+        a, b = synth.make_pair(5, 200, 300)
+        pv = torch.from_numpy(np.stack([a, b, a])).to(torch_dev)
+        nx = torch.from_numpy(np.stack([b, a, a])).to(torch_dev)
+        fr = torch.from_numpy(np.stack([a, b, a, b])).to(torch_dev)
+        res = {}
+        for jobs in (0, 1 << 30):
+            ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, jobs)
+            f1 = torch.empty((3, 200, 300, 2), dtype=torch.float32, device=torch_dev)
+            f2 = torch.empty((3, 200, 300, 2), dtype=torch.float32, device=torch_dev)
+            torch.cuda.synchronize()
+            nsof_lib.farneback_batch(pv, nx, f1, 3, 200, 300, nsof_lib.farneback.PARAMS_B, ctx=ctx)
+            nsof_lib.farneback_sequence(fr, f2, 4, 200, 300, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+            ctx.synchronize()
+            res[jobs] = (f1.cpu().numpy(), f2.cpu().numpy())
+        assert np.array_equal(res[0][0], res[1 << 30][0]) and np.array_equal(res[0][1], res[1 << 30][1])
+        assert np.array_equal(res[0][0][0], oracle.farneback(a, b, *B))
+    finally:
+        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 64)

@@ -371,3 +371,42 @@ def test_config3_roi_flow_pipeline_vs_oracle_chain(nsof_lib, ctx, oracle):
                 done.append((x0, y0, x1, y1))
             assert np.array_equal(gfl[k], canvas), (flag, k, float(np.abs(gfl[k] - canvas).max()))
         assert any(len(r) for r in rects[1:])
+
+
+@pytest.mark.gpu
+def test_roi_sequence_call_empty_tables_and_errors(nsof_lib, ctx):
+    """nsof_farneback_u8_roi_sequence_dev: no rectangles -> zeroed canvases and (0, 0); a count beyond the table or a
+    rectangle that leaves the frame -> NSOF_EINVAL with a message, nothing launched."""
+    import torch
+    from nsof import synth
+    dev = torch.device("cuda", ctx.device)
+    a, b = synth.make_pair(5, 200, 300)
+    frames = torch.from_numpy(np.stack([a, b, a])).to(dev)
+    counts = torch.zeros(3, dtype=torch.int32, device=dev)
+    rects = torch.zeros((3, 4, 4), dtype=torch.int32, device=dev)
+    flows = torch.full((2, 200, 300, 2), 7.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    assert nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx) == (0, 0)
+    ctx.synchronize()
+    assert float(flows.abs().max().item()) == 0.0
+    counts[1] = 9
+    with pytest.raises(nsof_lib.NsofError, match="rectangles"):
+        nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+    counts[1] = 1
+    rects[1, 0] = torch.tensor([10, 10, 400, 100], dtype=torch.int32)
+    with pytest.raises(nsof_lib.NsofError, match="leaves"):
+        nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+    # an overlapping pair of rectangles is pasted in order: the second one wins where they overlap
+    counts[1] = 2
+    rects[1, 0] = torch.tensor([20, 30, 180, 150], dtype=torch.int32)
+    rects[1, 1] = torch.tensor([100, 60, 280, 190], dtype=torch.int32)
+    n, px = nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+    ctx.synchronize()
+    assert (n, px) == (2, 160 * 120 + 180 * 130)
+    got = flows[0].cpu().numpy()
+    second = nsof_lib.calcOpticalFlowFarneback(np.ascontiguousarray(a[60:190, 100:280]), np.ascontiguousarray(b[60:190, 100:280]),
+                                               None, **nsof_lib.farneback.PARAMS_A.as_kwargs(), ctx=ctx)
+    first = nsof_lib.calcOpticalFlowFarneback(np.ascontiguousarray(a[30:150, 20:180]), np.ascontiguousarray(b[30:150, 20:180]),
+                                              None, **nsof_lib.farneback.PARAMS_A.as_kwargs(), ctx=ctx)
+    assert np.array_equal(got[60:190, 100:280], second) and np.array_equal(got[30:60, 20:180], first[:30])
+    assert not got[:30].any() and not got[190:].any() and float(np.abs(flows[1].cpu().numpy()).max()) == 0.0
