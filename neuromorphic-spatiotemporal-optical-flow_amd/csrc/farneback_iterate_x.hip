@@ -418,7 +418,11 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
         }
         XT_MARK(2);        // solve
         if (t == nimg + 1) break;
+#ifndef NSOF_X_ABL_PUB    // timing-only ablation: no second publish pass in the wave that straddles the segment boundary
         if (lag) publish(t);                       // right half: D(t), formed a window ago
+#else
+        if (lag && j >= 128) publish(t);
+#endif
         if (t + 1 < nimg) column_sums(t + 1);
         if (!lag) publish(t + 1);                  // left half: D(t+1), at once
         XT_MARK(0);        // column sums
@@ -580,8 +584,12 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
             };
             // both segments run the stream of the shorter one together; the rest of the longer (left) one follows
             const int nb0 = ncols >> 3, nba = nb0 < G::SEG1 / 8 ? nb0 : G::SEG1 / 8;
+#ifdef NSOF_X_ABL_SCAN   // timing-only ablation: the scanner runs two thirds of its blocks (what three 64-column segments would cost)
+            scan_blocks(0, nba * 2 / 3);
+#else
             scan_blocks(0, nba);
             if (nb0 > nba && !seg) scan_blocks(nba, nb0 - nba);
+#endif
             if (seg) cb[(step & 1) * 20 + l] = S;   // the row-end sums: the I/O wave hands them to the right neighbour
             else Smid = S;
         }
