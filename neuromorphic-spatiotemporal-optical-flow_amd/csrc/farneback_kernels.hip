@@ -593,39 +593,46 @@ __global__ __launch_bounds__(256) void k_prep_walk(const uint8_t* __restrict__ s
             h1 = row_filter<KS>(tk, KS, R, [&](int c) { return bb[c]; });
         }
     };
-    float H0[KS + 1], H1[KS + 1];
-    int base = 0;                                                  // source row of H0[0] / H1[0]
+    // The row-filtered pairs of the KS + 1 newest source rows live in a register ring with STATIC slots: source rows are
+    // taken strictly in order, row rstart + i into slot i % NB (the walk is unrolled NB times), and a destination row is
+    // emitted when the last row of its window, r0 + R + 1, has just entered -- its window rows then sit at the slots
+    // (u + 1 + q) % NB, q = 0..KS, known at compile time.  (Windows of consecutive destination rows overlap -- the launcher
+    // takes this kernel only while a destination step is shorter than the ring -- so no source row is filtered in vain.)
+    float H0[NB], H1[NB];
     const int dy_end = min(dy0 + seg_rows, hk);
-    for (int dy = dy0; dy < dy_end; dy++) {
-        int sy;
-        float b1;
-        lin_coord_y(dy, scale_y, sy, b1);
-        const float b0 = 1.f - b1;
-        const int r0 = clampi(sy, 0, H - 1), r1 = clampi(sy + 1, 0, H - 1);
-        const int want = r0 - R;
-        if (dy == dy0 || want - base > KS) {                       // (re)fill the whole window
+    int dy = dy0, sy;
+    float b1;
+    lin_coord_y(dy, scale_y, sy, b1);
+    int r0 = clampi(sy, 0, H - 1), r1 = clampi(sy + 1, 0, H - 1);
+    const int rstart = r0 - R;
+    int last = r0 - R + KS;                                        // the source row that completes the window of dy
+    for (int rb = 0; dy < dy_end && rb <= H + 2 * NB; rb += NB) {   // (bounded: at most H + KS + 1 source rows are walked)
 #pragma unroll
-            for (int i = 0; i <= KS; i++) hrow(want + i, H0[i], H1[i]);
-            base = want;
-        } else {
-            while (base < want) {                                   // wave-uniform: one more source row enters
-#pragma unroll
-                for (int i = 0; i < KS; i++) { H0[i] = H0[i + 1]; H1[i] = H1[i + 1]; }
-                hrow(base + KS + 1, H0[KS], H1[KS]);
-                base++;
+        for (int u = 0; u < NB; u++) {
+            if (dy >= dy_end) break;                               // wave-uniform
+            const int r = rstart + rb + u;
+            hrow(r, H0[u], H1[u]);
+            if (r == last) {                                       // wave-uniform
+                const float b0 = 1.f - b1;
+                const float B00 = col_filter<KS>(tk, KS, R, [&](int q) { return H0[(u + 1 + q) % NB]; });
+                const float B01 = col_filter<KS>(tk, KS, R, [&](int q) { return H1[(u + 1 + q) % NB]; });
+                float B10 = B00, B11 = B01;
+                if (r1 != r0) {
+                    B10 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H0[(u + 1 + q) % NB]; });
+                    B11 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H1[(u + 1 + q) % NB]; });
+                }
+                const float t0 = NSOF_MADD(B00, a0, B01 * a1);
+                const float t1 = NSOF_MADD(B10, a0, B11 * a1);
+                if (live) __builtin_nontemporal_store(NSOF_MADD(t0, b0, t1 * b1), dst + (size_t)dy * wk + dx);
+                dy++;
+                if (dy < dy_end) {
+                    lin_coord_y(dy, scale_y, sy, b1);
+                    r0 = clampi(sy, 0, H - 1);
+                    r1 = clampi(sy + 1, 0, H - 1);
+                    last = r0 - R + KS;
+                }
             }
         }
-        // rows of H0 / H1 are r0-R .. r0-R+KS; the window of r1 = r0+1 starts one entry later
-        const float B00 = col_filter<KS>(tk, KS, R, [&](int q) { return H0[q]; });
-        const float B01 = col_filter<KS>(tk, KS, R, [&](int q) { return H1[q]; });
-        float B10 = B00, B11 = B01;
-        if (r1 != r0) {
-            B10 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H0[q]; });
-            B11 = col_filter<KS>(tk, KS, R + 1, [&](int q) { return H1[q]; });
-        }
-        const float t0 = NSOF_MADD(B00, a0, B01 * a1);
-        const float t1 = NSOF_MADD(B10, a0, B11 * a1);
-        if (live) __builtin_nontemporal_store(NSOF_MADD(t0, b0, t1 * b1), dst + (size_t)dy * wk + dx);
     }
 }
 
@@ -1717,11 +1724,13 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
                 else NSOF_DECIM(8, 19, 8);
             }
 #undef NSOF_DECIM
-        } else if (scale_x >= 1.0 && scale_y >= 1.0 && (taps.ksize == 3 || taps.ksize == 5) &&
+        } else if (scale_x >= 1.0 && scale_y >= 1.0 && scale_y < taps.ksize &&
+                   (taps.ksize == 3 || taps.ksize == 5 || (taps.ksize == 9 && getenv("NSOF_PREP_WALK9") != nullptr)) &&
                    getenv("NSOF_PREP_NOWALK") == nullptr) {
-            // measured per 128-image launch at 1080p, pyr_scale 0.6: level 1 (3 taps) 656 -> 377 us, level 2 (5 taps) 407 ->
-            // 300 us against the direct kernel; with 9 taps (level 3: 415 x 233 outputs, 4.6 source rows per destination row)
-            // the walk is one long dependent chain on few waves and LOSES to the tiled kernel (985 vs 420 us): not used there
+            // measured per 128-image launch at 1080p, pyr_scale 0.6: level 1 (3 taps) 637 -> 334 us, level 2 (5 taps) 403 ->
+            // 266 us against the direct kernel (static-slot ring: 367 / 322 us with a shifting ring); with 9 taps (level 3:
+            // 415 x 233 outputs, 4.6 source rows per destination row) the walk still LOSES to the tiled kernel (624 vs 415 us):
+            // opt-in there for A/B runs (NSOF_PREP_WALK9)
             // segments of destination rows: long enough that the KS+1 rows of warm-up are a few per cent, short enough
             // that a small batch still has a few thousand waves
             int seg_rows = 32;
@@ -1733,7 +1742,8 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
     hipLaunchKernelGGL((k_prep_walk<KS>), grid, dim3(256), 0, ctx->stream, src, row_stride, img_stride, W, H, wk, hk, \
                        scale_x, scale_y, seg_rows, taps, out)
             if (taps.ksize == 3) NSOF_PREP_WALK(3);
-            else NSOF_PREP_WALK(5);
+            else if (taps.ksize == 5) NSOF_PREP_WALK(5);
+            else NSOF_PREP_WALK(9);
 #undef NSOF_PREP_WALK
         } else if (direct_ok) {
             dim3 grid((wk + 63) / 64, (hk + 3) / 4, n_img);
