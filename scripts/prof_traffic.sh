@@ -44,7 +44,11 @@ for k, v in acc.items():
         continue
     med = lambda a: sorted(a)[len(a) // 2]
     fk, wk = med(v["FETCH_SIZE"]), med(v["WRITE_SIZE"])
-    hbm = (2 * fk + wk) * 1024
+    # the x2 belongs to 16-B-per-lane reads only (guide: "other access widths are uncalibrated").  k_prep_same3_vec reads one
+    # dword per lane; doubled, its fetch would be 2.24x the source image although each wave issues loads for exactly 10 source
+    # rows per 8 it writes (1.25x) -- more than the kernel can request.  Undoubled it is 1.12x: 10 / 8 less what the L2 absorbs.
+    fmul = 1 if k == "k_prep_same3_vec" else 2
+    hbm = (fmul * fk + wk) * 1024
     out["kernels"][names[k]] = {"kernel": k, "fetch_kb": fk, "write_kb": wk, "algorithmic_bytes": alg[k],
                                 "hbm_bytes": int(hbm), "traffic_over_algorithmic": round(hbm / alg[k], 4)}
 json.dump(out, open(f"{repo}/gpurun_out/hbm_traffic_{tag}.json", "w"), indent=1)
