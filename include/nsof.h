@@ -270,6 +270,11 @@ int nsof_accum_run(nsof_accum* acc, int64_t first_slice, int64_t n_slices, int64
  * mode NSOF_SURFACE_STATE: g = uint8(255 * w), the build-defined frame of the joined events -> flow pipeline. */
 enum { NSOF_SURFACE_CURRENT = 0, NSOF_SURFACE_STATE = 1 };
 int nsof_accum_surface_u8_dev(nsof_accum* acc, int which, int mode, uint8_t* d_out, ptrdiff_t row_stride);
+/* nsof_accum_run + nsof_accum_surface_u8_dev of the state after the run's last slice, as one call: where the dense
+ * scheme-1 update runs, its last pass writes the frame itself (no separate pass over the array, one launch less); the
+ * frame is byte-identical to the two calls. */
+int nsof_accum_run_surface(nsof_accum* a, int64_t first_slice, int64_t n_slices, int which, int mode, uint8_t* d_out,
+                           ptrdiff_t row_stride);
 /* Checkpoint / resume (the reference persists only w_final, event_mem_sim.py:289-303): copy one array's state to /
  * from HOST memory -- w float32 [H][W], the refractory map int64 [H][W] (scheme 2; zeros otherwise) and the global
  * slice counter that times the snapshots.  NULL pointers are skipped. */

@@ -150,6 +150,28 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ p, size_t n, f
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
+// The surface as an 8-bit frame, one pixel (modes: see k_surface_gray).
+__device__ __forceinline__ uint8_t surface_gray_one(float ww, float neg_lam, int mode)
+{
+    double g;
+    if (mode == 0) {
+        const double r = (double)resistance_one(ww, neg_lam);
+        g = -3366.0 / log10(1.0 / r) - 306.0;
+    } else {
+        g = (double)(ww * 255.0f);
+    }
+    g = g < 0.0 ? 0.0 : (g > 255.0 ? 255.0 : g);   // NaN (I == 1 A exactly) cannot occur for R in [Ron, Roff]
+    return (uint8_t)g;
+}
+// Where the fused dense update leaves the frame of the state it has just written (out == nullptr: nowhere).
+struct SurfOut {
+    uint8_t* out;
+    long long stride;
+    int W;
+    float neg_lam;
+    int mode;
+};
+
 // Marks (pixel, slice bit); a pixel's first touch in this group enters the compact list once.  The list's counter is ONE
 // word: appended to per lane it serialises every first touch of a group at the L2 atomic unit (~10 ns each: 300 us for the
 // 33 k events of a 32-slice group at 1 M events/s, found with rocprofv3 in round 3), so the appends of a wave are
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(256) void k_update_sparse(float* __restrict__ w, un
 // is then bound by its one read and one write of the state instead of by 32 no-op evaluations per pixel.
 template <bool SIL_NOOP>
 __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, unsigned* __restrict__ mask, size_t n4,
-                                                       size_t n, int n_sl, float v_act, float v_sil)
+                                                       size_t n, int n_sl, float v_act, float v_sil, SurfOut so)
 {
     const Drive da = drive_of(v_act), ds = drive_of(v_sil);
     auto replay = [&](float ww, unsigned m) {
@@ -265,11 +287,29 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
             ww.z = replay(ww.z, mm.z);
             ww.w = replay(ww.w, mm.w);
             reinterpret_cast<float4*>(w)[i] = ww;
+            if (so.out) {   // the frame of the new state: saves the separate surface pass (4 B/px read again + a launch)
+                const uint8_t g0 = surface_gray_one(ww.x, so.neg_lam, so.mode), g1 = surface_gray_one(ww.y, so.neg_lam, so.mode);
+                const uint8_t g2 = surface_gray_one(ww.z, so.neg_lam, so.mode), g3 = surface_gray_one(ww.w, so.neg_lam, so.mode);
+                const size_t px = 4 * i;
+                const size_t yy = px / (size_t)so.W, xx = px - yy * (size_t)so.W;
+                if (xx + 3 < (size_t)so.W && ((so.stride | (long long)xx) & 3) == 0 && (reinterpret_cast<uintptr_t>(so.out) & 3) == 0) {
+                    *reinterpret_cast<unsigned*>(so.out + yy * so.stride + xx) =
+                        (unsigned)g0 | ((unsigned)g1 << 8) | ((unsigned)g2 << 16) | ((unsigned)g3 << 24);
+                } else {   // a group of 4 that straddles two rows, or an unaligned frame
+                    const uint8_t gg[4] = {g0, g1, g2, g3};
+                    for (int q = 0; q < 4; q++) {
+                        const size_t pq = px + q, yq = pq / (size_t)so.W, xq = pq - yq * (size_t)so.W;
+                        so.out[yq * so.stride + xq] = gg[q];
+                    }
+                }
+            }
         } else {
             for (size_t j = 4 * i; j < n; j++) {
                 const unsigned m = mask[j];
                 mask[j] = 0;
-                w[j] = replay(w[j], m);
+                const float wj = replay(w[j], m);
+                w[j] = wj;
+                if (so.out) so.out[(j / (size_t)so.W) * so.stride + j % (size_t)so.W] = surface_gray_one(wj, so.neg_lam, so.mode);
             }
         }
     }
@@ -538,16 +578,7 @@ __global__ __launch_bounds__(256) void k_surface_gray(const float* __restrict__ 
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W || y >= H) return;
-    const float ww = w[(size_t)y * W + x];
-    double g;
-    if (mode == 0) {
-        const double r = (double)resistance_one(ww, neg_lam);
-        g = -3366.0 / log10(1.0 / r) - 306.0;
-    } else {
-        g = (double)(ww * 255.0f);
-    }
-    g = g < 0.0 ? 0.0 : (g > 255.0 ? 255.0 : g);   // NaN (I == 1 A exactly) cannot occur for R in [Ron, Roff]
-    out[(ptrdiff_t)y * stride + x] = (uint8_t)g;
+    out[(ptrdiff_t)y * stride + x] = surface_gray_one(w[(size_t)y * W + x], neg_lam, mode);
 }
 
 // bincount_2d (event_mem_sim.py:100-104): events per pixel.
@@ -784,7 +815,20 @@ static int accum_stage(nsof_accum* a, const int16_t* x, const int16_t* y, const 
 }
 
 // Advance over staged slices [s_begin, s_begin + n_slices).
-static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64_t snap_every)
+static int accum_surface(nsof_accum* a, int which, const SurfOut& so)
+{
+    nsof_ctx* ctx = a->ctx;
+    dim3 grid((a->W + 255) / 256, a->H);
+    hipLaunchKernelGGL(k_surface_gray, grid, dim3(256), 0, ctx->stream, a->w[which], so.out, a->W, a->H, (ptrdiff_t)so.stride,
+                       so.neg_lam, so.mode);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
+// surf (optional): after the LAST slice of the call the surface of array surf_which goes to surf->out as an 8-bit frame --
+// fused into the last group's dense scheme-1 update where that kernel runs, a separate k_surface_gray launch otherwise.
+static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64_t snap_every, const SurfOut* surf = nullptr,
+                         int surf_which = 0)
 {
     nsof_ctx* ctx = a->ctx;
     if (s_begin < 0 || n_slices < 0 || (size_t)(s_begin + n_slices + 1) > a->h_rel.size())
@@ -800,6 +844,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
 
     int64_t s0 = s_begin;
     const int64_t s_end = s_begin + n_slices;
+    bool surf_done = false;
     if (a->use_graph < 0) {
         // measured (scripts/bench_accum_v2.py, 3840x2160, 1 M events/s): the replayed graph is 7-12 % SLOWER than the
         // plain launches (split 130 k vs 140 k slices/s, magnitude 224 k vs 255 k) -- a graph node costs as much as a
@@ -888,7 +933,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
             if (snap_after[gi])
                 if ((rc = accum_snapshot(a))) return rc;
         }
-        return NSOF_OK;
+        return surf ? accum_surface(a, surf_which, *surf) : NSOF_OK;
     }
     while (s0 < s_end) {
         // group = up to 32 slices, ending right after the next snapshot slice
@@ -899,7 +944,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
             if (to_snap < g) g = to_snap;
         }
         const long long ge0 = rel[s0], ge1 = rel[s0 + g], gn = ge1 - ge0;
-        NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 2 * sizeof(unsigned), ctx->stream));
+        if (sparse) NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 2 * sizeof(unsigned), ctx->stream));   // (the dense update has no list)
         unsigned* const l0 = sparse ? a->list[0] : nullptr;                      // the dense update reads no list
         unsigned* const l1 = sparse ? a->list[a->split ? 1 : 0] : nullptr;
         if (gn > 0) {
@@ -964,12 +1009,17 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
                                            a->w[i], a->mask[i], a->list[i], a->count + i, (int)g, v_act);
                 } else {
                     const size_t n4 = (a->npx + 3) / 4;
+                    SurfOut so{nullptr, 0, a->W, 0.f, 0};
+                    if (surf && i == surf_which && s0 + g == s_end) {   // the call's last group: leave the frame as well
+                        so = *surf;
+                        surf_done = true;
+                    }
                     if (dead_zone)
                         hipLaunchKernelGGL(k_update_dense<true>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream,
-                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v);
+                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v, so);
                     else
                         hipLaunchKernelGGL(k_update_dense<false>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream,
-                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v);
+                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v, so);
                 }
             }
             NSOF_HIP(ctx, hipGetLastError());
@@ -979,7 +1029,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         if (snap_every > 0 && (a->slice_counter - 1) % snap_every == 0)
             if ((rc = accum_snapshot(a))) return rc;
     }
-    return NSOF_OK;
+    return surf && !surf_done ? accum_surface(a, surf_which, *surf) : NSOF_OK;
 }
 
 extern "C" int nsof_accum_step_events(nsof_accum* a, const int16_t* x, const int16_t* y, const int8_t* p,
@@ -1007,13 +1057,16 @@ extern "C" int nsof_accum_run(nsof_accum* a, int64_t first_slice, int64_t n_slic
 extern "C" int nsof_accum_surface_u8_dev(nsof_accum* a, int which, int mode, uint8_t* d_out, ptrdiff_t row_stride)
 {
     if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W || mode < 0 || mode > 1) return NSOF_EINVAL;
-    nsof_ctx* ctx = a->ctx;
-    NSOF_HIP(ctx, hipSetDevice(ctx->device));
-    const float neg_lam = (float)(-std::log(ROFF / RON));
-    dim3 grid((a->W + 255) / 256, a->H);
-    hipLaunchKernelGGL(k_surface_gray, grid, dim3(256), 0, ctx->stream, a->w[which], d_out, a->W, a->H, row_stride, neg_lam, mode);
-    NSOF_HIP(ctx, hipGetLastError());
-    return NSOF_OK;
+    NSOF_HIP(a->ctx, hipSetDevice(a->ctx->device));
+    return accum_surface(a, which, SurfOut{d_out, (long long)row_stride, a->W, (float)(-std::log(ROFF / RON)), mode});
+}
+
+extern "C" int nsof_accum_run_surface(nsof_accum* a, int64_t first_slice, int64_t n_slices, int which, int mode, uint8_t* d_out,
+                                      ptrdiff_t row_stride)
+{
+    if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W || mode < 0 || mode > 1) return NSOF_EINVAL;
+    const SurfOut so{d_out, (long long)row_stride, a->W, (float)(-std::log(ROFF / RON)), mode};
+    return accum_advance(a, first_slice, n_slices, 0, &so, which);
 }
 
 // Checkpoint / resume: the whole state of one array is w (float32 [H][W]), its refractory map (int64 [H][W],

@@ -187,6 +187,19 @@ class Accumulator:
         self.ctx.check(self.ctx._lib.nsof_accum_run(self._p, int(first_slice), int(n_slices), int(snap_every)),
                        "accum_run")
 
+    def run_surface(self, first_slice, n_slices, d_out, which=0, row_stride=None, mode="state"):
+        """``run`` + ``surface_u8`` of the state after the last slice as one call (``nsof_accum_run_surface``): the dense
+        scheme-1 update's last pass writes the frame itself -- same bytes as the two calls, one pass over the array less."""
+        self.ctx.check(self.ctx._lib.nsof_accum_run_surface(self._p, int(first_slice), int(n_slices), which,
+                                                            {"current": 0, "state": 1}[mode], dev_ptr(d_out),
+                                                            self.W if row_stride is None else int(row_stride)),
+                       "accum_run_surface")
+
+    def run_frames(self, first_slice, n_frames, every, frames, which=0, mode="state"):
+        """``n_frames`` intervals of ``every`` slices, the surface after each into ``frames[k]`` (uint8 CUDA tensor [n][H][W])."""
+        for k in range(n_frames):
+            self.run_surface(first_slice + k * every, every, frames[k], which=which, row_stride=int(frames.stride(1)), mode=mode)
+
     def surface_u8(self, d_out, which=0, row_stride=None, mode="state"):
         """The current surface as an 8-bit frame written to DEVICE memory (torch uint8 tensor / address).
         ``mode``: "current" = the reference's current -> gray map (optical_flow_seg.py:426-431; saturates at 255 for

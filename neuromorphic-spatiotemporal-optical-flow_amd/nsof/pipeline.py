@@ -161,9 +161,7 @@ def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, a
     try:
         acc.set_events(x, y, p, t, idx)
         t0 = time.perf_counter()
-        for k in range(n_frames):
-            acc.run(k * snapshot_every, snapshot_every)
-            acc.surface_u8(frames[k])
+        acc.run_frames(0, n_frames, snapshot_every, frames)   # the frame of every interval from its last update pass
         ctx.synchronize()
         t1 = time.perf_counter()
         farneback_sequence(frames, flows, n_frames, H, W, params, ctx=ctx)
@@ -200,9 +198,7 @@ def events_to_flow_sequence_sharded(x, y, p, t, sensor_hw, params=None, slice_us
         acc = Accumulator(rows, w, 1, "split", active_v, silent_v, ctx=ctx, dense=dense)
         try:
             acc.set_events(xb, yb, pb, tb, idx)
-            for k in range(n_frames):
-                acc.run(k * every, every)
-                acc.surface_u8(out[k])
+            acc.run_frames(0, n_frames, every, out)
             ctx.synchronize()
         finally:
             acc.close()

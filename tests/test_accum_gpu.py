@@ -509,3 +509,37 @@ def test_config5_pipeline_flow_vs_oracle_chain(nsof_lib, ctx, oracle):
     fast = nsof_lib.calcOpticalFlowFarneback(gf[0], gf[1], None, *pa, ctx=ctx, exact=False)
     assert np.isfinite(fast).all()
     assert ctx.get_option(_lib.OPT_EXACT_ROWSUMS) == 1
+
+
+@pytest.mark.gpu
+def test_run_surface_equals_run_then_surface(nsof_lib, ctx):
+    """nsof_accum_run_surface (the dense update's last pass writes the 8-bit frame itself) == nsof_accum_run followed by
+    nsof_accum_surface_u8_dev, byte for byte: both modes, dense and sparse updates (the sparse one falls back to the separate
+    surface launch), widths that are not a multiple of 4, strided frames, a silent voltage outside the dead zone."""
+    import torch
+    from nsof import synth
+    from nsof.accumulator import Accumulator, slice_index_array
+    dev = torch.device("cuda", ctx.device)
+    for (H, W, silent, dense) in [(120, 160, 0.0, True), (77, 131, 0.0, True), (90, 202, 0.5, True), (120, 160, 0.0, False)]:
+        x, y, p, t = synth.make_events(9, W, H, 6000, 80_000, box=(20, 16))
+        idx = slice_index_array(t, 1000)
+        for mode in ("state", "current"):
+            frames = {}
+            for fused in (False, True):
+                acc = Accumulator(H, W, 1, "split", -6.0, silent, ctx=ctx, dense=dense)
+                try:
+                    acc.set_events(x, y, p, t, idx)
+                    buf = torch.zeros((2, H, W + 12), dtype=torch.uint8, device=dev)   # strided rows
+                    torch.cuda.synchronize()
+                    for k in range(2):
+                        if fused:
+                            acc.run_surface(k * 33, 33, buf[k], row_stride=W + 12, mode=mode)
+                        else:
+                            acc.run(k * 33, 33)
+                            acc.surface_u8(buf[k], row_stride=W + 12, mode=mode)
+                    ctx.synchronize()
+                    frames[fused] = buf.cpu().numpy()
+                finally:
+                    acc.close()
+            assert np.array_equal(frames[True], frames[False]), (H, W, silent, dense, mode)
+            assert frames[True][:, :, :W].any() and not frames[True][:, :, W:].any()
