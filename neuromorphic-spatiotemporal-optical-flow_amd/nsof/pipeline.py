@@ -112,8 +112,7 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
         acc.set_events(x, y, p, t, idx)
         t0 = time.perf_counter()
         for k in range(n_frames):
-            acc.run(k * snapshot_every, snapshot_every)
-            acc.surface_u8(frames[k], mode=surface_mode)
+            acc.run_surface(k * snapshot_every, snapshot_every, frames[k], mode=surface_mode)
             acc.block_current_dev(cfg.MEMSIZE, cur[k])
         counts, rtab = gating.roi_from_surface_dev(cur, n_frames, (rows, cols), (H, W), cfg, max_rects=max_rects, ctx=ctx)
         ctx.synchronize()
