@@ -568,8 +568,8 @@ def config5_leg(nsof, torch, local_rank):
     dense scheme-1 accumulator update of every 1 ms slice (events uploaded once) -> every 33 slices the surface as an
     8-bit frame -> Farneback (params A) between consecutive surface frames; nothing leaves HBM in between.
     "accumulator": slices/s with the roofline on SURVEY's definition (8 B/px/slice + 16 B/event: one read + one
-    write of w per slice) and on the bytes the fused design actually has to move (per 33 slices: two passes of
-    w read + w write + slice-mask read = 12 B/px, the 8-bit frame written by the second of them 1 B/px, 4 B/event), the CPU oracle's rate
+    write of w per slice) and on the bytes the fused design actually has to move (per 33 slices ONE pass: w read + w
+    write + two slice-mask words read = 16 B/px, the 8-bit frame written by the same pass 1 B/px, 4 B/event), the CPU oracle's rate
     for the same slices (1 thread / all cores) and the state parity after the sampled slices."""
     import numpy as np
     from nsof import pipeline, synth
@@ -586,7 +586,7 @@ def config5_leg(nsof, torch, local_rank):
         rate = n_sl / tm["accumulator_s"]
         npx, n_ev = H * W, int((t < n_sl * 1000 + t[0]).sum())
         survey_bytes = 8.0 * npx * n_sl + 16.0 * n_ev
-        fused_bytes = (n_sl / every) * (2 * 12.0 + 1.0) * npx + 4.0 * n_ev
+        fused_bytes = (n_sl / every) * (16.0 + 1.0) * npx + 4.0 * n_ev
         # parity + CPU rate on a bounded sample: the first k slices through the CPU oracle
         k = 20
         model, logical, physical, usable = O.host_cpu()
@@ -608,7 +608,7 @@ def config5_leg(nsof, torch, local_rank):
             "slices": n_sl, "events": n_ev, "x_realtime": round(rate / 1000.0, 1),
             "roofline_survey_definition": {"bytes_per_slice": round(survey_bytes / n_sl), "achieved": round(survey_bytes / tm["accumulator_s"] / 1e9, 1),
                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(survey_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3),
-                                           "note": "8 B/px/slice + 16 B/event; the fused pass replays 32 slices per read+write of w, so this exceeds 1"},
+                                           "note": "8 B/px/slice + 16 B/event; the fused pass replays up to 64 slices per read+write of w, so this exceeds 1"},
             "roofline_fused_bytes": {"bytes_per_slice": round(fused_bytes / n_sl), "achieved": round(fused_bytes / tm["accumulator_s"] / 1e9, 1),
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fused_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3)},
             "cpu_baseline": {"value": round(cpu1, 2), "value_all_cores": round(cpua, 2), "unit": "slices/s", "cores": 1,

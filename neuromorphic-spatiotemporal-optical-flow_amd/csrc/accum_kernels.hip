@@ -195,7 +195,8 @@ __device__ __forceinline__ void mark(unsigned* mask, unsigned* list, unsigned* c
 // indices of the group's slice boundaries (n_sl+1 entries), relative to ev0.
 __global__ __launch_bounds__(256) void k_scatter_v1(const short* __restrict__ x, const short* __restrict__ y,
                                                      long long ev0, long long n_ev, const long long* __restrict__ bounds,
-                                                     int n_sl, int W, unsigned* mask, unsigned* list, unsigned* count)
+                                                     int n_sl, int W, unsigned* mask, unsigned* list, unsigned* count,
+                                                     unsigned* mask_hi)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n_ev;
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256) void k_scatter_v1(const short* __restrict__ x,
         const int mid = (lo + hi) >> 1;
         if (bounds[mid] <= e) lo = mid; else hi = mid;
     }
-    mark(mask, list, count, (unsigned)y[e] * (unsigned)W + (unsigned)x[e], 1u << lo, live);
+    // slices 32..63 of a group (dense update only: n_sl <= 32 otherwise) go to the second mask word
+    mark(lo < 32 ? mask : mask_hi, list, count, (unsigned)y[e] * (unsigned)W + (unsigned)x[e], 1u << (lo & 31), live);
 }
 
 // Scheme 2 (:237-269), one slice: eligible <=> next_ok[pix] <= t_first; eligible pixels are
@@ -259,15 +261,19 @@ __global__ __launch_bounds__(256) void k_update_sparse(float* __restrict__ w, un
 // is then bound by its one read and one write of the state instead of by 32 no-op evaluations per pixel.
 template <bool SIL_NOOP>
 __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, unsigned* __restrict__ mask, size_t n4,
-                                                       size_t n, int n_sl, float v_act, float v_sil, SurfOut so)
+                                                       size_t n, int n_sl, float v_act, float v_sil, SurfOut so,
+                                                       unsigned* __restrict__ mask_hi)
 {
     const Drive da = drive_of(v_act), ds = drive_of(v_sil);
-    auto replay = [&](float ww, unsigned m) {
+    // m: slices 0..31 of the group, mh: slices 32..63 (groups of up to 64 slices: one pass over the array where a frame
+    // interval of 33 slices took two)
+    auto replay = [&](float ww, unsigned m, unsigned mh) {
         if (SIL_NOOP) {
             for (; m; m &= m - 1) ww = update_drive(ww, da);
+            for (; mh; mh &= mh - 1) ww = update_drive(ww, da);
         } else {
             for (int s = 0; s < n_sl; s++) {
-                const bool act = (m >> s) & 1u;
+                const bool act = s < 32 ? (m >> s) & 1u : (mh >> (s - 32)) & 1u;
                 Drive d;
                 d.ka = act ? da.ka : ds.ka;
                 d.s = act ? da.s : ds.s;
@@ -282,10 +288,15 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
             float4 ww = reinterpret_cast<float4*>(w)[i];
             const uint4 mm = reinterpret_cast<uint4*>(mask)[i];
             if (mm.x | mm.y | mm.z | mm.w) reinterpret_cast<uint4*>(mask)[i] = make_uint4(0, 0, 0, 0);
-            ww.x = replay(ww.x, mm.x);
-            ww.y = replay(ww.y, mm.y);
-            ww.z = replay(ww.z, mm.z);
-            ww.w = replay(ww.w, mm.w);
+            uint4 mh = make_uint4(0, 0, 0, 0);
+            if (mask_hi) {
+                mh = reinterpret_cast<uint4*>(mask_hi)[i];
+                if (mh.x | mh.y | mh.z | mh.w) reinterpret_cast<uint4*>(mask_hi)[i] = make_uint4(0, 0, 0, 0);
+            }
+            ww.x = replay(ww.x, mm.x, mh.x);
+            ww.y = replay(ww.y, mm.y, mh.y);
+            ww.z = replay(ww.z, mm.z, mh.z);
+            ww.w = replay(ww.w, mm.w, mh.w);
             reinterpret_cast<float4*>(w)[i] = ww;
             if (so.out) {   // the frame of the new state: saves the separate surface pass (4 B/px read again + a launch)
                 const uint8_t g0 = surface_gray_one(ww.x, so.neg_lam, so.mode), g1 = surface_gray_one(ww.y, so.neg_lam, so.mode);
@@ -305,9 +316,10 @@ __global__ __launch_bounds__(256) void k_update_dense(float* __restrict__ w, uns
             }
         } else {
             for (size_t j = 4 * i; j < n; j++) {
-                const unsigned m = mask[j];
+                const unsigned m = mask[j], mh = mask_hi ? mask_hi[j] : 0u;
                 mask[j] = 0;
-                const float wj = replay(w[j], m);
+                if (mask_hi) mask_hi[j] = 0;
+                const float wj = replay(w[j], m, mh);
                 w[j] = wj;
                 if (so.out) so.out[(j / (size_t)so.W) * so.stride + j % (size_t)so.W] = surface_gray_one(wj, so.neg_lam, so.mode);
             }
@@ -606,6 +618,7 @@ struct nsof_accum {
     float* w[2] = {nullptr, nullptr};
     long long* next_ok[2] = {nullptr, nullptr};
     unsigned* mask[2] = {nullptr, nullptr};
+    unsigned* mask_hi = nullptr;   // slices 32..63 of a dense scheme-1 group (allocated on first use, kept zero between groups)
     unsigned* list[2] = {nullptr, nullptr};
     size_t list_cap = 0;
     unsigned* count = nullptr;  // [2]
@@ -651,7 +664,7 @@ extern "C" void nsof_accum_destroy(nsof_accum* a)
     for (int i = 0; i < 2; i++) {
         hipFree(a->w[i]); hipFree(a->next_ok[i]); hipFree(a->mask[i]); hipFree(a->list[i]); hipFree(a->snap[i]);
     }
-    hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
+    hipFree(a->mask_hi); hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
     hipFree(a->d_slices); hipFree(a->d_groups); hipFree(a->d_gi);
     if (a->graph) hipGraphExecDestroy(a->graph);
     delete a;
@@ -935,9 +948,17 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         }
         return surf ? accum_surface(a, surf_which, *surf) : NSOF_OK;
     }
+    // the dense scheme-1 update takes groups of up to 64 slices (two mask words per pixel): a 33-slice frame interval is one
+    // pass over the array instead of two
+    const bool wide = a->scheme == 1 && !sparse;
+    if (wide && !a->mask_hi) {
+        if ((rc = accum_alloc(ctx, (void**)&a->mask_hi, a->npx * sizeof(unsigned) + 16))) return rc;
+        NSOF_HIP(ctx, hipMemsetAsync(a->mask_hi, 0, a->npx * sizeof(unsigned) + 16, ctx->stream));
+    }
+    const int64_t max_group = wide ? 2 * MAX_GROUP : MAX_GROUP;
     while (s0 < s_end) {
-        // group = up to 32 slices, ending right after the next snapshot slice
-        int64_t g = s_end - s0 < MAX_GROUP ? s_end - s0 : MAX_GROUP;
+        // group = up to max_group slices, ending right after the next snapshot slice
+        int64_t g = s_end - s0 < max_group ? s_end - s0 : max_group;
         if (snap_every > 0) {
             const int64_t c = a->slice_counter;
             const int64_t to_snap = (c % snap_every == 0) ? 1 : (snap_every - c % snap_every) + 1;
@@ -951,7 +972,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
             nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
             if (a->scheme == 1) {
                 hipLaunchKernelGGL(k_scatter_v1, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx,
-                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], l0, a->count);
+                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], l0, a->count, a->mask_hi);
             } else if (!a->v2_per_slice) {
                 hipLaunchKernelGGL(k_scatter_v2g, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx, a->dy,
                                    a->dp, ge0, gn, a->dbounds + s0, (int)g, a->W, a->split ? 1 : 0, a->mask[0], l0,
@@ -1016,10 +1037,12 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
                     }
                     if (dead_zone)
                         hipLaunchKernelGGL(k_update_dense<true>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream,
-                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v, so);
+                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v, so,
+                                           g > MAX_GROUP ? a->mask_hi : nullptr);
                     else
                         hipLaunchKernelGGL(k_update_dense<false>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream,
-                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v, so);
+                                           a->w[i], a->mask[i], n4, a->npx, (int)g, v_act, a->silent_v, so,
+                                           g > MAX_GROUP ? a->mask_hi : nullptr);
                 }
             }
             NSOF_HIP(ctx, hipGetLastError());

@@ -543,3 +543,40 @@ def test_run_surface_equals_run_then_surface(nsof_lib, ctx):
                     acc.close()
             assert np.array_equal(frames[True], frames[False]), (H, W, silent, dense, mode)
             assert frames[True][:, :, :W].any() and not frames[True][:, :, W:].any()
+
+
+@pytest.mark.gpu
+def test_dense_groups_of_64_slices(nsof_lib, ctx, oracle):
+    """The dense scheme-1 update fuses up to 64 slices per pass (two mask words per pixel): runs whose groups exceed 32
+    slices equal the event-pixel path bit for bit (silent voltage in the dead zone) and the oracle within the usual
+    tolerance (silent voltage outside it: every pixel integrates in every slice, in slice order)."""
+    from nsof import synth
+    from nsof.accumulator import Accumulator, slice_index_array
+    H, W = 90, 131
+    x, y, p, t = synth.make_events(17, W, H, 9000, 150_000, box=(20, 16))
+    idx = slice_index_array(t, 1000)
+    n = len(idx) - 1
+    assert n >= 140
+    ws = {}
+    for dense in (False, True):
+        acc = Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=ctx, dense=dense)
+        try:
+            acc.set_events(x, y, p, t, idx)
+            acc.run(0, 70)          # dense: one group of 64 + one of 6
+            acc.run(70, 33)         # one group of 33
+            acc.run(103, n - 103)
+            ws[dense] = acc.w()
+        finally:
+            acc.close()
+    assert np.array_equal(ws[True], ws[False])
+    ref = oracle.accum_simulate(x, y, p, t, H, W, 1, "split", 1000, -6.0, 0.0)
+    assert np.abs(ws[True] - ref["w_final"]).max() <= W_ATOL
+    acc = Accumulator(H, W, 1, "split", -6.0, 0.5, ctx=ctx)       # leaks in every silent slice: the every-pixel pass
+    try:
+        acc.set_events(x, y, p, t, idx)
+        acc.run(0, n)
+        w_leak = acc.w()
+    finally:
+        acc.close()
+    ref = oracle.accum_simulate(x, y, p, t, H, W, 1, "split", 1000, -6.0, 0.5)
+    assert np.abs(w_leak - ref["w_final"]).max() <= 2e-6, float(np.abs(w_leak - ref["w_final"]).max())
