@@ -2,7 +2,7 @@
 """Accumulator benchmark (BASELINE.json config 5): synthetic 3840x2160 event stream at 1 M events/s,
 1 ms slices, scheme 1, active_v=-6, silent_v=0.  Reports slices/s for
   sparse : the default path (silent_v in the dead zone -> only event pixels are visited)
-  dense  : every pixel visited, up to 32 slices fused per pass (nsof_accum_set_dense) -- the HBM-roofline run
+  dense  : every pixel visited, up to 64 slices fused per pass (nsof_accum_set_dense) -- the HBM-roofline run
 and the CPU oracle (oracle/accum_ref.c, 1 thread) on a bounded number of slices.  One JSON line."""
 import argparse
 import json
@@ -66,9 +66,9 @@ def main():
         ent = {"slices_per_s": round(nsl / best, 1), "wall_ms": round(best * 1e3, 2), "kernel_ms": round(kms, 3),
                "kernel_launches": kn}
         if mode == "dense":
-            # fused pass: w read+written (8 B/px) + mask read (4 B/px, + rare clears) per group of <= 32 slices
-            groups = (nsl + 31) // 32
-            alg = groups * W * H * 12 + n * 5
+            # fused pass: w read+written (8 B/px) + two mask words read (8 B/px, + rare clears) per group of <= 64 slices
+            groups = (nsl + 63) // 64
+            alg = groups * W * H * 16 + n * 5
             ent.update(algorithmic_bytes=alg, achieved_gbs=round(alg / (kms * 1e-3) / 1e9, 1),
                        frac_of_8tbs=round(alg / (kms * 1e-3) / 8e12, 4),
                        per_slice_equivalent_gbs=round(nsl * W * H * 8 / (kms * 1e-3) / 1e9, 1))
