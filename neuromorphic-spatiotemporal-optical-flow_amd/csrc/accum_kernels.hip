@@ -239,9 +239,11 @@ __global__ __launch_bounds__(256) void k_scatter_v2(const short* __restrict__ x,
 // Fused state update over the touched pixels only (silent_v inside the dead zone).
 __global__ __launch_bounds__(256) void k_update_sparse(float* __restrict__ w, unsigned* __restrict__ mask,
                                                         const unsigned* __restrict__ list,
-                                                        const unsigned* __restrict__ count, int n_sl, float v_act)
+                                                        const unsigned* __restrict__ count, int n_sl, float v_act,
+                                                        unsigned* zero_next)
 {
     const unsigned n = *count;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0;   // the NEXT group's list counter (other parity)
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const unsigned pix = list[i];
         unsigned m = mask[pix];
@@ -381,12 +383,14 @@ __device__ __forceinline__ unsigned refractory_walk(unsigned e, long long& ok, c
 
 __global__ __launch_bounds__(256) void k_update_sparse_v2(float* __restrict__ w, unsigned* __restrict__ mask,
                                                            long long* __restrict__ next_ok, const unsigned* __restrict__ list,
-                                                           const unsigned* __restrict__ count, RefrTab tab, float v_act)
+                                                           const unsigned* __restrict__ count, RefrTab tab, float v_act,
+                                                           unsigned* zero_next)
 {
     __shared__ long long tf[32], tn[32];
     if (threadIdx.x < 32) { tf[threadIdx.x] = tab.t_first[threadIdx.x]; tn[threadIdx.x] = tab.t_next[threadIdx.x]; }
     __syncthreads();
     const unsigned n = *count;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0;   // the NEXT group's list counter (other parity)
     const Drive da = drive_of(v_act);
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const unsigned pix = list[i];
@@ -703,7 +707,7 @@ extern "C" int nsof_accum_create(nsof_ctx* ctx, int height, int width, int schem
     a->active_v = active_v; a->silent_v = silent_v;
     a->npx = (size_t)height * width;
     const int narr = a->split ? 2 : 1;
-    int rc = accum_alloc(ctx, (void**)&a->count, 2 * sizeof(unsigned));
+    int rc = accum_alloc(ctx, (void**)&a->count, 4 * sizeof(unsigned));   // [parity][array]: groups alternate, see accum_advance
     for (int i = 0; i < narr && !rc; i++) {
         rc = accum_alloc(ctx, (void**)&a->w[i], (a->npx + 4) * sizeof(float));
         if (!rc) rc = accum_alloc(ctx, (void**)&a->mask[i], (a->npx + 4) * sizeof(unsigned));
@@ -956,6 +960,10 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         NSOF_HIP(ctx, hipMemsetAsync(a->mask_hi, 0, a->npx * sizeof(unsigned) + 16, ctx->stream));
     }
     const int64_t max_group = wide ? 2 * MAX_GROUP : MAX_GROUP;
+    // List counters of the event-pixel update: two sets used alternately.  A group's update kernels zero the OTHER set -- the
+    // one the next group's scatter appends to -- so the per-group 8-byte memset (a launch of its own) is gone: one per call.
+    int par = 0;
+    if (sparse && s0 < s_end) NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 4 * sizeof(unsigned), ctx->stream));
     while (s0 < s_end) {
         // group = up to max_group slices, ending right after the next snapshot slice
         int64_t g = s_end - s0 < max_group ? s_end - s0 : max_group;
@@ -965,18 +973,20 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
             if (to_snap < g) g = to_snap;
         }
         const long long ge0 = rel[s0], ge1 = rel[s0 + g], gn = ge1 - ge0;
-        if (sparse) NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 2 * sizeof(unsigned), ctx->stream));   // (the dense update has no list)
+        unsigned* const cnt = a->count + 2 * par;          // this group's counters; (the dense update has no list)
+        unsigned* const cnt_next = a->count + 2 * (par ^ 1);
+        if (sparse && gn == 0) NSOF_HIP(ctx, hipMemsetAsync(cnt_next, 0, 2 * sizeof(unsigned), ctx->stream));   // no update kernel will
         unsigned* const l0 = sparse ? a->list[0] : nullptr;                      // the dense update reads no list
         unsigned* const l1 = sparse ? a->list[a->split ? 1 : 0] : nullptr;
         if (gn > 0) {
             nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
             if (a->scheme == 1) {
                 hipLaunchKernelGGL(k_scatter_v1, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx,
-                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], l0, a->count, a->mask_hi);
+                                   a->dy, ge0, gn, a->dbounds + s0, (int)g, a->W, a->mask[0], l0, cnt, a->mask_hi);
             } else if (!a->v2_per_slice) {
                 hipLaunchKernelGGL(k_scatter_v2g, dim3((unsigned)((gn + 255) / 256)), dim3(256), 0, ctx->stream, a->dx, a->dy,
                                    a->dp, ge0, gn, a->dbounds + s0, (int)g, a->W, a->split ? 1 : 0, a->mask[0], l0,
-                                   a->count, a->mask[a->split ? 1 : 0], l1, a->count + 1);
+                                   cnt, a->mask[a->split ? 1 : 0], l1, cnt + 1);
             } else {
                 for (int64_t s = 0; s < g; s++) {
                     const long long lo = rel[s0 + s], hi = rel[s0 + s + 1];
@@ -987,14 +997,14 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
                     if (a->split) {
                         hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
                                            hi - lo, 1, t_first, t_next, a->W, bit, a->next_ok[0], a->mask[0],
-                                           l0, a->count);
+                                           l0, cnt);
                         hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
                                            hi - lo, 0, t_first, t_next, a->W, bit, a->next_ok[1], a->mask[1],
-                                           l1, a->count + 1);
+                                           l1, cnt + 1);
                     } else {
                         hipLaunchKernelGGL(k_scatter_v2, grid, dim3(256), 0, ctx->stream, a->dx, a->dy, a->dp, lo,
                                            hi - lo, -1, t_first, t_next, a->W, bit, a->next_ok[0], a->mask[0],
-                                           l0, a->count);
+                                           l0, cnt);
                     }
                 }
             }
@@ -1016,7 +1026,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
                     if (sparse) {
                         if (gn > 0)
                             hipLaunchKernelGGL(k_update_sparse_v2, dim3(grid_for((size_t)gn, 1024)), dim3(256), 0, ctx->stream,
-                                               a->w[i], a->mask[i], a->next_ok[i], a->list[i], a->count + i, tab, v_act);
+                                               a->w[i], a->mask[i], a->next_ok[i], a->list[i], cnt + i, tab, v_act, cnt_next + i);
                     } else if (dead_zone) {
                         hipLaunchKernelGGL(k_update_dense_v2<true>, dim3(grid_for(n4, 8192)), dim3(256), 0, ctx->stream, a->w[i],
                                            a->mask[i], a->next_ok[i], n4, a->npx, (int)g, tab, v_act, a->silent_v);
@@ -1027,7 +1037,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
                 } else if (sparse) {
                     if (gn > 0)
                         hipLaunchKernelGGL(k_update_sparse, dim3(grid_for((size_t)gn, 1024)), dim3(256), 0, ctx->stream,
-                                           a->w[i], a->mask[i], a->list[i], a->count + i, (int)g, v_act);
+                                           a->w[i], a->mask[i], a->list[i], cnt + i, (int)g, v_act, cnt_next + i);
                 } else {
                     const size_t n4 = (a->npx + 3) / 4;
                     SurfOut so{nullptr, 0, a->W, 0.f, 0};
@@ -1049,6 +1059,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         }
         a->slice_counter += g;
         s0 += g;
+        if (sparse) par ^= 1;
         if (snap_every > 0 && (a->slice_counter - 1) % snap_every == 0)
             if ((rc = accum_snapshot(a))) return rc;
     }
