@@ -617,7 +617,7 @@ struct nsof_accum {
     nsof_ctx* ctx = nullptr;
     int H = 0, W = 0, scheme = 1, split = 0;
     float active_v = 0, silent_v = 0;
-    bool force_dense = false;
+    int force_dense = 0;   // nsof_accum_set_dense: 0 automatic, 1 every-pixel pass, -1 event-pixel update (where exact)
     size_t npx = 0;
     float* w[2] = {nullptr, nullptr};
     long long* next_ok[2] = {nullptr, nullptr};
@@ -722,7 +722,7 @@ extern "C" int nsof_accum_create(nsof_ctx* ctx, int height, int width, int schem
 extern "C" int nsof_accum_set_dense(nsof_accum* a, int force_dense)
 {
     if (!a) return NSOF_EINVAL;
-    a->force_dense = force_dense != 0;
+    a->force_dense = force_dense > 0 ? 1 : (force_dense < 0 ? -1 : 0);
     return NSOF_OK;
 }
 
@@ -856,7 +856,16 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
     int rc;
     const std::vector<long long>& rel = a->h_rel;
     const bool dead_zone = !(a->silent_v < VOFF) && !(a->silent_v > VON);
-    const bool sparse = dead_zone && !a->force_dense;
+    // Scheme 1 with the silent voltage in the dead zone: the event-pixel update (lists, groups of 32 slices) and the
+    // every-pixel pass (groups of 64 slices, no lists) give the same bits; which one is faster depends on the sensor size.
+    // Measured with a frame every 33 slices (scripts/accum_mode_probe.py): 1280x720 0.39 vs 0.75-0.89 ms per 30 frames,
+    // 3840x2160 0.97 vs 1.21 ms for the every-pixel pass -- both are launch bound and it needs half the launches; its cost
+    // grows with the pixel count (16 B/px per 64 slices), so beyond ~12 M pixels the event-pixel update takes over.
+    static const size_t auto_dense_px = [] {
+        const char* e = getenv("NSOF_ACCUM_AUTO_DENSE_PX");
+        return e ? (size_t)atoll(e) : (size_t)12 << 20;
+    }();
+    const bool sparse = dead_zone && a->force_dense <= 0 && (a->force_dense < 0 || !(a->scheme == 1 && a->npx <= auto_dense_px));
     const float v_act = a->scheme == 1 ? a->active_v : a->silent_v + a->active_v;
 
     int64_t s0 = s_begin;

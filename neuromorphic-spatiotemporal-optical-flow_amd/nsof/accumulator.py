@@ -136,7 +136,7 @@ class Accumulator:
     """Device-resident array state (w, refractory maps) that can be advanced chunk by chunk."""
 
     def __init__(self, height, width, version=1, polarity="split", active_v=-8.0, silent_v=0.0, *, ctx=None,
-                 dense=False):
+                 dense=None):
         if version not in (1, 2):
             raise NsofValueError("version must be 1 or 2")
         if polarity not in ("split", "magnitude"):
@@ -148,8 +148,8 @@ class Accumulator:
         self.ctx.check(self.ctx._lib.nsof_accum_create(self.ctx.ptr, self.H, self.W, version, int(self.split),
                                                        float(active_v), float(silent_v), C.byref(p)), "accum_create")
         self._p = p
-        if dense:
-            self.ctx.check(self.ctx._lib.nsof_accum_set_dense(self._p, 1), "accum_set_dense")
+        if dense is not None:   # None: automatic; True: the every-pixel pass; False: the event-pixel update where it is exact
+            self.ctx.check(self.ctx._lib.nsof_accum_set_dense(self._p, 1 if dense else -1), "accum_set_dense")
 
     def reset(self):
         self.ctx.check(self.ctx._lib.nsof_accum_reset(self._p), "accum_reset")
@@ -282,7 +282,7 @@ class Accumulator:
 
 
 def simulate(events, version=1, slice_us=1_000, active_v=-8.0, silent_v=0.0, save_video=False, polarity="split",
-             *, sensor_size=None, out_prefix=None, ctx=None, dense=False):
+             *, sensor_size=None, out_prefix=None, ctx=None, dense=None):
     """``simulate`` of event_mem_sim.py:164-286.
 
     ``events``: an HDF5 path with a ``/CD/events`` group (as the reference) or a tuple ``(x, y, p, t)`` of arrays.

@@ -70,10 +70,11 @@ def test_dense_path_equals_sparse_path(nsof_lib, ctx, name):
     kw = dict(version=int(d["version"]), slice_us=int(d["slice_us"]), active_v=float(d["active_v"]),
               silent_v=float(d["silent_v"]), polarity=str(d["polarity"]), sensor_size=(H, W), ctx=ctx)
     ev = (d["x"], d["y"], d["p"], d["t"])
-    a = nsof_lib.simulate(ev, **kw)
-    b = nsof_lib.simulate(ev, dense=True, **kw)
+    a = nsof_lib.simulate(ev, dense=False, **kw)      # the event-pixel update
+    b = nsof_lib.simulate(ev, dense=True, **kw)       # the every-pixel pass
+    c = nsof_lib.simulate(ev, **kw)                   # automatic choice
     for k in a:
-        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
 
 
 def test_chunked_stepping_equals_one_shot(nsof_lib, ctx):
