@@ -183,6 +183,22 @@ struct LRGeom {
     static constexpr size_t SMEM = sizeof(double) * (5 * PLANE + 2 * 5 * SPLANE);
 };
 
+#ifdef NSOF_LR_TIMING
+// Tuning build only (scripts/build_variant.sh lrt farneback_iterate_lat.hip -DNSOF_LR_TIMING; scripts/lr_timing.py): where one
+// workgroup of the row scan spends its time.  g_lrt: [role 0..2][work cycles, barrier-wait cycles], [6] steps, [7] kernel
+// shader cycles of wave 0, [8] the same span in s_memrealtime ticks (100 MHz): [7] / [8] = the shader clock in units of 100 MHz.
+__device__ unsigned long long g_lrt[16];
+extern "C" int nsof_debug_lrtiming(unsigned long long* out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lrt), sizeof(g_lrt)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lrt), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 template <class F, int... Ks>
 __device__ __forceinline__ void lr_steps(F& step, int s, int T, std::integer_sequence<int, Ks...>)
 {
@@ -267,8 +283,21 @@ __global__ __launch_bounds__(LRGeom<LR_ROWS>::THREADS) void k_lat_rowscan(const 
     }
     // solver role: pixel (sj, sr) of the tile
     const int sj = li & (LR_TW - 1), sr = li / LR_TW;
+#ifdef NSOF_LR_TIMING
+    const bool lt_on = blockIdx.x == 1 && blockIdx.z == 0 && W >= 1024;
+    const bool lt_lead = lt_on && (tid == 0 || tid == LR_CHAIN || tid == LR_CHAIN + LR_SOLVE);
+    unsigned long long lt_work = 0, lt_wait = 0, lt_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long lt_t0 = lt_prev, lt_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     auto step = [&](auto kc, int s) {
         constexpr int K = decltype(kc)::value;
+#ifdef NSOF_LR_TIMING
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            lt_wait += now - lt_prev;
+            lt_prev = now;
+        }
+#endif
         if (role == 0) {
 #if !(defined(NSOF_LR_ABL) && NSOF_LR_ABL == 2)   // timing-only build: no chain
             if (chain_on) {
@@ -320,10 +349,28 @@ __global__ __launch_bounds__(LRGeom<LR_ROWS>::THREADS) void k_lat_rowscan(const 
                 }
             }
         }
+#ifdef NSOF_LR_TIMING
+        {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            lt_work += now - lt_prev;
+            lt_prev = now;
+        }
+#endif
         __syncthreads();
     };
     // step T only solves the last tile (its chain / ring work is harmless); unrolled by the prefetch depth (register sets)
     for (int s = 0; s <= T; s += LR_DEPTH) lr_steps(step, s, T, std::make_integer_sequence<int, LR_DEPTH>{});
+#ifdef NSOF_LR_TIMING
+    if (lt_lead) {
+        atomicAdd(&g_lrt[2 * role], lt_work);
+        atomicAdd(&g_lrt[2 * role + 1], lt_wait);
+        if (tid == 0) {
+            atomicAdd(&g_lrt[6], (unsigned long long)(T + 1));
+            atomicAdd(&g_lrt[7], __builtin_amdgcn_s_memtime() - lt_t0);
+            atomicAdd(&g_lrt[8], __builtin_amdgcn_s_memrealtime() - lt_r0);
+        }
+    }
+#endif
 }
 
 template <int MH, int ROWS>
