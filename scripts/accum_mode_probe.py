@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Scheme-1 accumulator with a surface frame every 33 slices: the event-pixel update (dense=False) against the every-pixel
+pass (dense=True: groups of 64 slices) at 1280x720 and 3840x2160 -- which one the automatic mode should take."""
 import sys, time
 sys.path[:0]=["/root/repo","/root/repo/neuromorphic-spatiotemporal-optical-flow_amd"]
 import os; os.environ.setdefault("NSOF_SKIP_BUILD","1")
