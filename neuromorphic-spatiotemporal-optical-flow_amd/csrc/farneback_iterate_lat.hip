@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_lat_matrices(const float* __restrict__ 
 constexpr int LC_WAVES = 8, LC_R = 32, LC_PASS = LC_WAVES * LC_R;
 template <bool HET>
 __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __restrict__ M, int W, int H, int m,
-                                                               double* __restrict__ V, const nsof_het_item* __restrict__ items)
+                                                               double* __restrict__ V, const nsof_het_item* __restrict__ items,
+                                                               unsigned* err)
 {
     __shared__ double carry[64];
     __shared__ int turns_done;
@@ -123,10 +124,12 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
         if (y0 + LC_PASS < H) fetch(y0 + LC_PASS);                     // this wave's rows of the next pass: in flight early
         // wait for this wave's turn (every earlier turn belongs to a resident wave of this workgroup; bounded all the same)
         const int my = p * LC_WAVES + wave;
-        for (int spin = 0; spin < (1 << 22); spin++) {
+        int spin = 0;
+        for (; spin < (1 << 22); spin++) {
             if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&turns_done)) == my) break;
             __builtin_amdgcn_s_sleep(1);
         }
+        if (spin == (1 << 22) && lane == 0) atomicOr(err, 4u);   // cannot happen; reported as NSOF_EDEVICE at nsof_synchronize
         asm volatile("" ::: "memory");
         double vs = *reinterpret_cast<volatile double*>(&carry[lane]);
         const int n = min(LC_R, H - y0);
@@ -418,12 +421,15 @@ int lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const double* V, 
 int nsof_launch_iterate_lat(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                             const float* flow_in, float* flow_out, int W, int H, int winsize, float* M, double* V)
 {
+    unsigned long long* carry_unused;
+    unsigned *tickets_unused, *err;   // the time-out word of the bounded spin in k_lat_colsum (checked at nsof_synchronize)
+    if (int rc = nsof_xsync_reserve(ctx, 0, &carry_unused, &tickets_unused, &err)) return rc;
     {
         nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
         hipLaunchKernelGGL(k_lat_matrices<false>, dim3((W + 63) / 64, (H + 3) / 4, n_pairs), dim3(256), 0, ctx->stream, R0, R1,
                            pair_stride, flow_in, W, H, M, nullptr);
         hipLaunchKernelGGL(k_lat_colsum<false>, dim3((W + 63) / 64, 5, n_pairs), dim3(64 * LC_WAVES), 0, ctx->stream, (const float*)M, W, H,
-                           winsize / 2, V, nullptr);
+                           winsize / 2, V, nullptr, err);
     }
     return lat_rowscan(ctx, n_pairs, W, H, H, V, winsize, flow_out, nullptr, false);
 }
@@ -431,12 +437,15 @@ int nsof_launch_iterate_lat(nsof_ctx* ctx, int n_pairs, const float* R0, const f
 int nsof_launch_iterate_lat_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
                                 const float* flow_in, float* flow_out, bool final, int winsize, float* M, double* V)
 {
+    unsigned long long* carry_unused;
+    unsigned *tickets_unused, *err;   // the time-out word of the bounded spin in k_lat_colsum (checked at nsof_synchronize)
+    if (int rc = nsof_xsync_reserve(ctx, 0, &carry_unused, &tickets_unused, &err)) return rc;
     {
         nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
         hipLaunchKernelGGL(k_lat_matrices<true>, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_items), dim3(256), 0, ctx->stream, R, R,
                            (size_t)0, flow_in, 0, 0, M, d_items);
         hipLaunchKernelGGL(k_lat_colsum<true>, dim3((max_w + 63) / 64, 5, n_items), dim3(64 * LC_WAVES), 0, ctx->stream, (const float*)M, 0, 0,
-                           winsize / 2, V, d_items);
+                           winsize / 2, V, d_items, err);
     }
     return lat_rowscan(ctx, n_items, 0, 0, max_h, V, winsize, flow_out, d_items, final);
 }

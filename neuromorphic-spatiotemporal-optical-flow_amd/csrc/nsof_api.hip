@@ -70,7 +70,7 @@ int nsof_xsync_check(nsof_ctx* ctx)
     NSOF_HIP(ctx, hipMemcpy(&w, ctx->x_sync + 256, sizeof(w), hipMemcpyDeviceToHost));
     if (w) {
         NSOF_HIP(ctx, hipMemset(ctx->x_sync + 256, 0, sizeof(w)));
-        return nsof_set_error(ctx, NSOF_EDEVICE, "exact-order iteration: a strip's carry never arrived (flags %u); results are invalid", w);
+        return nsof_set_error(ctx, NSOF_EDEVICE, "exact-order iteration: a hand-over between workgroups / waves never arrived (flags %u); results are invalid", w);
     }
     return NSOF_OK;
 }
