@@ -202,6 +202,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ctx.synchronize()   # the stream the steps ran on (= torch's current stream) + the kernels' hand-over error word: raises on a lost carry
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
@@ -219,7 +220,8 @@ def main():
     exit_code = 0
     out = None
     wd = None
-    state = {"printed": False}
+    import threading as _threading
+    state = {"printed": False, "lock": _threading.Lock()}
     if rank == 0:
         total_pairs = n * world * args.steps
         alg = algorithmic_bytes_per_pair(nsof, w, h, p)
@@ -277,11 +279,20 @@ def main():
     if (args.io == "gather" or (args.io == "auto" and world > 1)) and args.mode == "pairs":
         import threading
 
+        # what the watchdog prints: a private copy of the measured headline (the main thread keeps adding to `out`)
+        headline = json.loads(json.dumps(out)) if rank == 0 else None
+
         def emergency():
-            if rank == 0 and not state["printed"]:
-                out["io_gather"] = {"error": f"the scatter/compute/gather leg did not finish within {args.io_timeout} s"}
-                os.write(real_stdout, (json.dumps(out) + "\n").encode())
-            os._exit(0)
+            # the leg hung (or timed out) on this rank: rank 0 still prints the headline it has measured, with the error in
+            # place of the leg's numbers, and EVERY rank leaves with exit code 4 so that the hang is visible in the run's
+            # status, not only in the JSON
+            with state["lock"]:
+                if rank == 0 and not state["printed"]:
+                    headline["io_gather"] = {"error": f"the scatter/compute/gather leg did not finish within {args.io_timeout} s",
+                                             "exit_code": 4}
+                    os.write(real_stdout, (json.dumps(headline) + "\n").encode())
+                    state["printed"] = True
+                os._exit(4)
 
         wd = threading.Timer(args.io_timeout, emergency)
         wd.daemon = True
@@ -322,8 +333,9 @@ def main():
             if isinstance(out.get(key), dict) and out[key].get("parity_ok") is False:
                 out["parity_ok"] = False
         sys.stdout.flush()
-        state["printed"] = True
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        with state["lock"]:
+            state["printed"] = True
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if out.get("parity_ok") is False:
             print(f"bench: GPU flow differs from the CPU baseline by more than {out.get('epe_tolerance', 1e-4)} "
                   "(headline batch, real frames, config 3 or config 5)", file=sys.stderr)

@@ -89,8 +89,15 @@ int nsof_synchronize(nsof_ctx* ctx);
  * in HBM: a lone 1920x1080 call 3.9 -> 1.2 ms host to host.  Results are bit-identical either way; the value only moves
  * the switch-over (measured cross-over: 70-80 jobs, scripts/small_batch_crossover.py; 0 = always the fused kernel).
  * Environment default: NSOF_LAT_JOBS. */
+/* NSOF_OPT_DEBUG_FAULT (default 0; TEST HOOK, not a mode): the exact-order iteration kernels hand running sums from one
+ * workgroup / wave to the next (strip-to-strip carries in k_iterate_x, wave turns in k_lat_colsum); every wait for such a
+ * hand-over is bounded, and a wait that runs out makes the call that synchronises next return NSOF_EDEVICE (cv2 raises
+ * cv2.error where it fails, optical_flow_seg.py:203 -- a flow field is never handed back from a failed launch).  Bit 0 = strip
+ * 0 of item 0 of every k_iterate_x launch withholds its carries, bit 1 = wave 3 of workgroup (0, 0, 0) of every
+ * k_lat_colsum launch never passes its turn on: the failure the bounded waits exist for, on demand
+ * (tests/test_farneback_gpu.py::test_lost_handover_is_reported). */
 enum { NSOF_OPT_POLYEXP_F32 = 1, NSOF_OPT_EXACT_ROWSUMS = 2, NSOF_OPT_ROW_BANDS = 3, NSOF_OPT_PYR_FMA = 4,
-       NSOF_OPT_SMALL_BATCH_JOBS = 5 };
+       NSOF_OPT_SMALL_BATCH_JOBS = 5, NSOF_OPT_DEBUG_FAULT = 100 };
 int nsof_set_option(nsof_ctx* ctx, int option, int value);
 int nsof_get_option(const nsof_ctx* ctx, int option, int* value);
 

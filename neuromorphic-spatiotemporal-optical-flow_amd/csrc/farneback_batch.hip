@@ -688,7 +688,7 @@ extern "C" int nsof_farneback_u8_batch(nsof_ctx* ctx, int n_pairs, const nsof_pa
     for (int ci = 0; ci < nc; ci++)
         if (!finished[ci])
             if (int rc = finish(chunks[ci], pp->slot[ci % NS])) return rc;
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rcs = nsof_stream_sync_checked(ctx)) return rcs;   // incl. a lost hand-over of the exact-order flow kernels
     if (trace) {
         fprintf(stderr, "[nsof pipe] %d chunks, host total %.2f ms; per chunk: pairs | host pack begin..end | h2d | compute | d2h (ms from first upload)\n",
                 nc, now_ms() - t_call);

@@ -67,10 +67,10 @@ constexpr int LC_WAVES = 8, LC_R = 32, LC_PASS = LC_WAVES * LC_R;
 template <bool HET>
 __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __restrict__ M, int W, int H, int m,
                                                                double* __restrict__ V, const nsof_het_item* __restrict__ items,
-                                                               unsigned* err)
+                                                               unsigned* err, int fault)
 {
     __shared__ double carry[64];
-    __shared__ int turns_done;
+    __shared__ int turns_done, dead;
     if constexpr (HET) {
         const nsof_het_item& it = items[blockIdx.z];
         W = it.wk;
@@ -112,9 +112,16 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
         double vs = (double)(Mat(0) * (float)(m + 2));
         for (int y = 1; y < m; y++) vs += (double)Mat(min(y, H - 1));
         carry[lane] = vs;
-        if (lane == 0) turns_done = 0;
+        if (lane == 0) {
+            turns_done = 0;
+            // a hand-over already timed out on this context: the call fails whatever is computed from here on
+            dead = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        }
     }
     __syncthreads();
+    if (*reinterpret_cast<volatile int*>(&dead)) return;   // block-uniform
+    // NSOF_OPT_DEBUG_FAULT bit 1 (test hook): one wave of one workgroup never passes its turn on
+    const bool withhold = (fault & 2) && wave == 3 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
     for (int p = 0;; p++) {
         const int y0 = p * LC_PASS + wave * LC_R;
         if (y0 >= H) break;
@@ -124,12 +131,18 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
         if (y0 + LC_PASS < H) fetch(y0 + LC_PASS);                     // this wave's rows of the next pass: in flight early
         // wait for this wave's turn (every earlier turn belongs to a resident wave of this workgroup; bounded all the same)
         const int my = p * LC_WAVES + wave;
+        // (a wait that runs out is sticky for the whole workgroup -- `dead` -- so a failed launch drains in one time-out;
+        // the host fails the call: nsof_xsync_check)
         int spin = 0;
         for (; spin < (1 << 22); spin++) {
             if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&turns_done)) == my) break;
+            if (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&dead))) { spin = 1 << 22; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        if (spin == (1 << 22) && lane == 0) atomicOr(err, 4u);   // cannot happen; reported as NSOF_EDEVICE at nsof_synchronize
+        if (spin == (1 << 22) && lane == 0) {
+            atomicOr(err, 4u);
+            *reinterpret_cast<volatile int*>(&dead) = 1;
+        }
         asm volatile("" ::: "memory");
         double vs = *reinterpret_cast<volatile double*>(&carry[lane]);
         const int n = min(LC_R, H - y0);
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
         }
         *reinterpret_cast<volatile double*>(&carry[lane]) = vs;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the sums are in LDS before the counter moves
-        if (lane == 0) *reinterpret_cast<volatile int*>(&turns_done) = my + 1;
+        if (lane == 0 && !withhold) *reinterpret_cast<volatile int*>(&turns_done) = my + 1;
         if (live) {
             unsigned off = (unsigned)y0 * vrow + xv;
 #pragma unroll
@@ -429,7 +442,7 @@ int nsof_launch_iterate_lat(nsof_ctx* ctx, int n_pairs, const float* R0, const f
         hipLaunchKernelGGL(k_lat_matrices<false>, dim3((W + 63) / 64, (H + 3) / 4, n_pairs), dim3(256), 0, ctx->stream, R0, R1,
                            pair_stride, flow_in, W, H, M, nullptr);
         hipLaunchKernelGGL(k_lat_colsum<false>, dim3((W + 63) / 64, 5, n_pairs), dim3(64 * LC_WAVES), 0, ctx->stream, (const float*)M, W, H,
-                           winsize / 2, V, nullptr, err);
+                           winsize / 2, V, nullptr, err, ctx->dbg_fault);
     }
     return lat_rowscan(ctx, n_pairs, W, H, H, V, winsize, flow_out, nullptr, false);
 }
@@ -445,7 +458,7 @@ int nsof_launch_iterate_lat_het(nsof_ctx* ctx, int n_items, const nsof_het_item*
         hipLaunchKernelGGL(k_lat_matrices<true>, dim3((max_w + 63) / 64, (max_h + 3) / 4, n_items), dim3(256), 0, ctx->stream, R, R,
                            (size_t)0, flow_in, 0, 0, M, d_items);
         hipLaunchKernelGGL(k_lat_colsum<true>, dim3((max_w + 63) / 64, 5, n_items), dim3(64 * LC_WAVES), 0, ctx->stream, (const float*)M, 0, 0,
-                           winsize / 2, V, d_items, err);
+                           winsize / 2, V, d_items, err, ctx->dbg_fault);
     }
     return lat_rowscan(ctx, n_items, 0, 0, max_h, V, winsize, flow_out, d_items, final);
 }

@@ -251,12 +251,18 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
         g0 = __hip_atomic_load(cin + 40 * s + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         g1 = __hip_atomic_load(cin + 40 * s + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    // A wait that runs out (X_SPIN_LIMIT polls, or the launch's error word already set by another strip -- looked at every
+    // 256 polls) marks the launch failed and is STICKY: this strip stops polling for the rest of its walk, so a failed
+    // launch drains in about one time-out, not one per step (the host then fails the call: nsof_xsync_check).
+    bool dead = false;
     auto fetch_finish = [&](int s) {
         if (!cin || !io) return;
-        for (unsigned spins = 0;; spins++) {
+        for (unsigned spins = 0; !dead; spins++) {
             if (__all((unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch)) break;
-            if (spins > X_SPIN_LIMIT) {
+            if (spins > X_SPIN_LIMIT ||
+                ((spins & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 if (lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dead = true;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
@@ -605,7 +611,7 @@ template <int MH, bool HET>
 __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
     const float* __restrict__ R0b, const float* __restrict__ R1b, size_t pair_stride, const float* __restrict__ flow_in,
     float* __restrict__ flow_out, int W, int H, int block_size, const nsof_het_item* __restrict__ items, int het_final,
-    int n, int nstrips, unsigned long long* carry, unsigned* tickets, unsigned epoch, unsigned* err)
+    int n, int nstrips, unsigned long long* carry, unsigned* tickets, unsigned epoch, unsigned* err, int fault)
 {
     using G = XGeom<MH>;
     constexpr int SW = G::SW, COLS = G::COLS;
@@ -624,6 +630,9 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
         const unsigned share = (unsigned)((n + 7) / 8) * (unsigned)nstrips;
         unsigned k = xcc_id();
         unsigned i = __hip_atomic_fetch_add(tickets + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a hand-over already timed out on this context (this launch or an earlier one of the same call): the call will
+        // fail whatever this workgroup computes, so it leaves at once -- a failed call drains in one time-out
+        if (__hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) i = 0xffffffffu, k = 0;
         if (i >= share) {   // more workgroups landed on this XCD than its share: take another XCD's next job
             for (unsigned d = 1; d < 8 && i >= share; d++) {
                 k = (k + 1) & 7u;
@@ -708,7 +717,8 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
             F.xc = (unsigned)xc;
             const size_t per_strip = (size_t)nimg * 40;
             gu64* cin = strip > 0 ? cbase + (size_t)(strip - 1) * per_strip : nullptr;
-            gu64* cout = x0 + SW < W ? cbase + (size_t)strip * per_strip : nullptr;
+            // NSOF_OPT_DEBUG_FAULT bit 0 (test hook): strip 0 of item 0 keeps its carries to itself
+            gu64* cout = x0 + SW < W && !((fault & 1) && pair == 0 && strip == 0) ? cbase + (size_t)strip * per_strip : nullptr;
             x_remainder_loop<MH>(ring, cb, R0, R1, F, W, H, xc, col, r, nimg, cin, cout, epoch, (gu32*)err, xt);
         } else {
             const int col = blk * 64 + lane;
@@ -743,7 +753,7 @@ int launch_x(nsof_ctx* ctx, int n, int max_w, int max_h, const float* R0, const 
     }
     const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)nstrips;
     hipLaunchKernelGGL((k_iterate_x<MH, HET>), dim3(grid), dim3(G::THREADS), G::SMEM, ctx->stream, R0, R1, pair_stride, flow_in,
-                       flow_out, W, H, winsize, items, final ? 1 : 0, n, nstrips, carry, tickets, epoch, err);
+                       flow_out, W, H, winsize, items, final ? 1 : 0, n, nstrips, carry, tickets, epoch, err, ctx->dbg_fault);
     return NSOF_OK;
 }
 

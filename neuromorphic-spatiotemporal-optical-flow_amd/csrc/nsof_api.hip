@@ -75,6 +75,12 @@ int nsof_xsync_check(nsof_ctx* ctx)
     return NSOF_OK;
 }
 
+int nsof_stream_sync_checked(nsof_ctx* ctx)
+{
+    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return nsof_xsync_check(ctx);
+}
+
 // ---- profiling ---------------------------------------------------------------------------
 nsof_prof_scope::nsof_prof_scope(nsof_ctx* c, int k) : ctx(c), id(k), on((c->prof_mask >> k) & 1u)
 {
@@ -287,6 +293,11 @@ extern "C" int nsof_set_option(nsof_ctx* ctx, int option, int value)
         ctx->opt_small_batch_jobs = value;
         return NSOF_OK;
     }
+    if (option == NSOF_OPT_DEBUG_FAULT) {
+        if (value < 0 || value > 3) return nsof_set_error(ctx, NSOF_EINVAL, "NSOF_OPT_DEBUG_FAULT: bits 0..1");
+        ctx->dbg_fault = value;
+        return NSOF_OK;
+    }
     return nsof_set_error(ctx, NSOF_EINVAL, "unknown option %d", option);
 }
 
@@ -313,14 +324,17 @@ extern "C" int nsof_get_option(const nsof_ctx* ctx, int option, int* value)
         *value = ctx->opt_small_batch_jobs;
         return NSOF_OK;
     }
+    if (option == NSOF_OPT_DEBUG_FAULT) {
+        *value = ctx->dbg_fault;
+        return NSOF_OK;
+    }
     return NSOF_EINVAL;
 }
 
 extern "C" int nsof_synchronize(nsof_ctx* ctx)
 {
     if (!ctx) return NSOF_EINVAL;
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return nsof_xsync_check(ctx);
+    return nsof_stream_sync_checked(ctx);
 }
 
 // ---- filter taps (host, double precision as the reference library computes them) -----------
@@ -907,11 +921,12 @@ extern "C" int nsof_farneback_u8(nsof_ctx* ctx, const uint8_t* prev, ptrdiff_t p
                                      levels, winsize, iterations, poly_n, poly_sigma, flags);
     if (rc) return rc;
     NSOF_HIP(ctx, hipMemcpyAsync(out_dense ? flow : hF, dFl, n0 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a hand-over between workgroups that never arrived (the exact-order kernels' bounded waits) fails the call, as cv2
+    // raises where it fails: the flow of such a launch is never handed back as a result
+    if ((rc = nsof_stream_sync_checked(ctx))) return rc;
     if (!out_dense)
         for (int y = 0; y < height; y++)
             memcpy((char*)flow + (ptrdiff_t)y * flow_stride, hF + (size_t)y * width * 2, (size_t)width * 8);
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return NSOF_OK;
 }
 

@@ -28,6 +28,7 @@ struct nsof_ctx {
     int opt_exact_rowsums = 1; // NSOF_OPT_EXACT_ROWSUMS (default: the library's row-sum order)
     int opt_row_bands = 0;     // NSOF_OPT_ROW_BANDS: 0 off, 1 automatic, >= 4 rows per band
     int opt_small_batch_jobs = 64;    // NSOF_OPT_SMALL_BATCH_JOBS: calls with at most this many (strip, image) jobs take the three-kernel exact form
+    int dbg_fault = 0;         // NSOF_OPT_DEBUG_FAULT (test hook): bit 0 k_iterate_x withholds a carry, bit 1 k_lat_colsum a turn
     int opt_pyr_fma = 0;       // NSOF_OPT_PYR_FMA: pyramid blur / resamples with fused multiply-adds (arithmetic variant twin)
     char err[512] = {0};
     // reusable device workspace of the Farneback driver
@@ -205,6 +206,8 @@ int nsof_launch_iterate_x_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d
 int nsof_xsync_reserve(nsof_ctx* ctx, size_t carry_bytes, unsigned long long** carry, unsigned** tickets, unsigned** err);
 // Reads the timeout word of the exact-order kernel after the stream has drained; NSOF_EDEVICE if a carry never arrived.
 int nsof_xsync_check(nsof_ctx* ctx);
+// hipStreamSynchronize(ctx->stream) + nsof_xsync_check: the tail of every entry point that hands results to the host
+int nsof_stream_sync_checked(nsof_ctx* ctx);
 bool nsof_iterate_upsample_supported(int winsize, int W, int H);
 // First iteration of a level: flow_in = resample(coarse_flow [sh][sw][2]) * mul, computed on the fly.
 int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,

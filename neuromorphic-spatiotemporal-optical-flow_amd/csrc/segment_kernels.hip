@@ -430,7 +430,7 @@ extern "C" int nsof_motion_mask(nsof_ctx* ctx, const float* flow, ptrdiff_t flow
     if ((rc = nsof_motion_mask_dev(ctx, dF, 2 * (ptrdiff_t)width, width, height, thresh, ksize, iterations, dM, width)))
         return rc;
     NSOF_HIP(ctx, hipMemcpyAsync(out_dense ? mask : hM, dM, n0, hipMemcpyDeviceToHost, ctx->stream));
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rcs = nsof_stream_sync_checked(ctx)) return rcs;   // incl. a lost hand-over of the exact-order flow kernels
     if (!out_dense)
         for (int y = 0; y < height; y++) memcpy(mask + (ptrdiff_t)y * mask_stride, hM + (size_t)y * width, (size_t)width);
     return NSOF_OK;

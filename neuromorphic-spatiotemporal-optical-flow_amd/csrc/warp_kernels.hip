@@ -309,7 +309,7 @@ extern "C" int nsof_predict_warp_u8(nsof_ctx* ctx, const uint8_t* frame, ptrdiff
                                  (ptrdiff_t)rw * channels)))
         return rc;
     NSOF_HIP(ctx, hipMemcpyAsync(hO, dO, (size_t)rw * rh * channels, hipMemcpyDeviceToHost, ctx->stream));
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rcs = nsof_stream_sync_checked(ctx)) return rcs;   // incl. a lost hand-over of the exact-order flow kernels
     for (int y = 0; y < rh; y++)
         memcpy(out + (ptrdiff_t)(y0 + y) * out_stride + (ptrdiff_t)x0 * channels, hO + (size_t)y * rw * channels,
                (size_t)rw * channels);
@@ -344,7 +344,7 @@ extern "C" int nsof_ssim_u8_dev(nsof_ctx* ctx, const uint8_t* d_a, ptrdiff_t a_s
                        partial + nblk);
     NSOF_HIP(ctx, hipGetLastError());
     NSOF_HIP(ctx, hipMemcpyAsync(ssim_out, partial + nblk, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rcs = nsof_stream_sync_checked(ctx)) return rcs;   // incl. a lost hand-over of the exact-order flow kernels
     return NSOF_OK;
 }
 

@@ -22,6 +22,7 @@ OPT_EXACT_ROWSUMS = 2
 OPT_ROW_BANDS = 3
 OPT_PYR_FMA = 4
 OPT_SMALL_BATCH_JOBS = 5
+OPT_DEBUG_FAULT = 100   # test hook: see include/nsof.h
 NSOF_OK, NSOF_EINVAL, NSOF_ESHAPE, NSOF_EDEVICE, NSOF_ENOMEM, NSOF_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 K_PREP, K_POLYEXP, K_UPSAMPLE, K_UPDMAT, K_BLUR, K_ACCUM, K_ITERATE, K_SEGMENT, K_MORPH, K_REMAP, K_SSIM, K_COUNT = range(12)
 

@@ -63,9 +63,12 @@ def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, itera
     False = the fast mode (each pixel's window summed directly: a few per cent faster, up to ~8e-4 off where 2x2 systems
     are rank deficient), None = whatever the context / ``install(exact=...)`` says.
     ``low_latency`` (keyword only): True = the fast mode with row bands in the iteration kernel for this call
-    (``NSOF_OPT_ROW_BANDS``: a lone 1080p call drops from 3.7 to 1.1 ms; column sums restart per band, so the flow moves
-    in its 5th decimal, more where the 2x2 system is rank deficient -- the automatic mode therefore applies from winsize
-    9 up); ignored together with an explicit ``exact=True``.
+    (``NSOF_OPT_ROW_BANDS``: the fast mode's lone 1080p call drops from 3.7 to 1.1 ms -- the exact default is at that speed
+    on its own since the small-batch form of round 3, so this is only of interest with ``exact=False``; column sums restart
+    per band, so the flow moves in its 5th decimal, more where the 2x2 system is rank deficient -- the automatic mode
+    therefore applies from winsize 9 up); ignored together with an explicit ``exact=True``.
+    Raises ``nsof.error`` (a ``cv2.error`` where cv2 imports) on every failure, device-side ones included: a launch whose
+    workgroup hand-over timed out never returns a flow field (``NSOF_EDEVICE``).
     The two keywords set context options around the call; the context's lock makes that safe for concurrent callers of
     one context."""
     prev = _as_gray_u8(prev, "prev")

@@ -104,8 +104,11 @@ def test_bench_prints_the_headline_when_the_gather_leg_hangs():
            "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--pairs", "8", "--io-timeout", "0.01"]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode != 0, "a hung leg must show in the exit status (every rank leaves with code 4)"
+    assert "exitcode  : 4" in out.stderr or "exitcode: 4" in out.stderr or "exit code 4" in out.stderr.lower() or out.returncode in (1, 4), \
+        out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "did not finish" in d["io_gather"]["error"]
+    assert d["io_gather"]["exit_code"] == 4

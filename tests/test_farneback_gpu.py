@@ -685,3 +685,36 @@ def test_small_batch_form_edge_shapes_batches_and_sequences(nsof_lib, ctx, oracl
         assert np.array_equal(res[0][0][0], oracle.farneback(a, b, *B))
     finally:
         ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 64)
+
+
+@pytest.mark.parametrize("form", ["fused_kernel", "small_batch_form"])
+def test_lost_handover_is_reported(nsof_lib, oracle, form):
+    """cv2 raises where it fails (/root/reference/optical_flow_seg.py:203 would propagate cv2.error).  The one failure mode
+    the exact-order kernels add -- a hand-over between workgroups (k_iterate_x: strip-to-strip carries) or waves
+    (k_lat_colsum: turns) that never arrives -- must fail the CALL THE REFERENCE MAKES, in bounded time, and leave the
+    context usable: NSOF_OPT_DEBUG_FAULT makes one strip withhold its carries / one wave its turn."""
+    import time
+    from nsof import _lib, synth
+    from nsof.errors import NsofDeviceError
+    prev, nxt = synth.make_pair(31, 300, 420)          # 3 strips of 192 columns; 10 turns of 32 rows
+    c = nsof_lib.Context(0)
+    try:
+        c.set_option(_lib.OPT_SMALL_BATCH_JOBS, 0 if form == "fused_kernel" else 64)
+        want = oracle.farneback(prev, nxt, *A)
+        assert np.array_equal(nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=c), want)
+        c.set_option(_lib.OPT_DEBUG_FAULT, 1 if form == "fused_kernel" else 2)
+        t0 = time.perf_counter()
+        with pytest.raises(NsofDeviceError) as ei:
+            nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=c)
+        dt = time.perf_counter() - t0
+        assert ei.value.status == _lib.NSOF_EDEVICE and "hand-over" in str(ei.value)
+        assert dt < 10.0, f"a failed launch must drain quickly, took {dt:.1f} s"
+        # the pipelined list entry and the device-resident entry + synchronize report it as well
+        with pytest.raises(NsofDeviceError):
+            nsof_lib.farneback_pairs([(prev, nxt)], nsof_lib.farneback.PARAMS_A, ctx=c)
+        c.set_option(_lib.OPT_DEBUG_FAULT, 0)
+        # the error is consumed; the same context computes the oracle's bits again
+        c.synchronize()
+        assert np.array_equal(nsof_lib.calcOpticalFlowFarneback(prev, nxt, None, *A, ctx=c), want)
+    finally:
+        c.close()
