@@ -39,15 +39,21 @@ namespace {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(3))) int lds_int;   // a flag word in LDS, accessed as such (ds_read / ds_write, no flat access)
 
 // XCD (0..7) this wave runs on: HW_REG_XCC_ID (id 20), bits 3:0.
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
 
-// Geometry: 11 waves.  Waves 0-2 consumers (192 output columns), wave 3 the scanner, waves 4-6 / 8-10 producers of rows
-// 0,1 / 2,3 of every step for ring columns 0..191 (thread <-> column), wave 7 the producer of all four rows for ring columns
-// 192..207 (lane <-> (row, column)): half the work of the others, and the wave that shares SIMD 3 with the scanner (waves
-// go to SIMD wave % 4), whose chain would otherwise starve a full producer wave there -- or be starved by it.
-// 154 VGPRs (3 waves per SIMD), 160 KB of LDS: ring 2m+9 rows x 208 x 20 B, D / g 2 x 31 KB.  (A 4th consumer wave for 240 of
+// Geometry: 12 waves (round 4; 11 before).  Waves 0-2 consumers (192 output columns: column sums, D, and row 0 of the step's
+// solves), wave 3 the scanner, waves 4-6 / 8-10 producers of rows 0,1 / 2,3 of every step for ring columns 0..191 (thread <->
+// column), wave 7 the producer of all four rows for ring columns 192..207 (lane <-> (row, column)) which is also the strip's
+// I/O wave and solves row 1, wave 11 the solver of rows 2,3.  Waves go to SIMD wave % 4: SIMD 3 holds the scanner, the I/O
+// wave and the solver.  Why: the step is bound by vector issue, and with the solves in the consumers SIMDs 0-2 carried
+// ~1144 issue units per step against ~363 on SIMD 3 (ISA mix of the three roles, scripts/isa_mix.py); a single wave issues
+// one vector instruction per ~8 clocks whatever its SIMD has free, so the solves are spread over three roles by ROW --
+// 256 pairs 1080p, same box: 28.12 -> 27.29 ms per step (-3 %), coarse levels -6 / -7 % (their jobs are short and the
+// pipelined start-up below counts for more).
+// 168 VGPRs (3 waves per SIMD), 160 KB of LDS: ring 2m+9 rows x 208 x 20 B, D / g 2 x 31 KB.  (A 4th consumer wave for 240 of
 // 256 columns makes 4 waves on one SIMD: 128 VGPRs, ~190 spilled registers, 1.6x slower; and no room for the second buffer.)
 template <int MH>
 struct XGeom {
@@ -64,8 +70,19 @@ struct XGeom {
     static constexpr int SEG0 = NSOF_X_SEG0, SEG1 = SW - SEG0;   // the strip's two scan segments (see x_scanner_loop)
     static_assert(SEG0 % 8 == 0 && SEG1 % 8 == 0 && SEG0 >= SEG1 && SEG1 > 0, "segments: whole 8-column blocks, the left one not shorter");
     static constexpr int SVW = SW + 2;                      // doubles per (row, plane) of D / g (even: 16-byte rows)
-    static constexpr int WAVES = NCW + 1 + 2 * NB + 1;
+    static constexpr int WAVES = NCW + 1 + 2 * NB + 1 + 1;   // ... + the solver wave (the last one: SIMD 3, next to the scanner)
     static constexpr int THREADS = 64 * WAVES;
+#ifndef NSOF_X_CQ
+#define NSOF_X_CQ 1
+#endif
+#ifndef NSOF_X_IOQ
+#define NSOF_X_IOQ 1
+#endif
+    // Who solves which of a step's four rows: the consumers rows [0, CQ) (own column, before they overwrite it), the I/O
+    // wave rows [CQ, CQ + IOQ), the solver wave the rest.  A wave issues one vector instruction per ~8 clocks whatever the
+    // SIMD has free, so the split balances the LENGTH of the per-wave instruction streams, not only the SIMDs.
+    static constexpr int CQ = NSOF_X_CQ, IOQ = NSOF_X_IOQ;
+    static_assert(CQ >= 0 && IOQ >= 0 && CQ + IOQ <= 4, "rows of a step");
     static constexpr size_t SV1_BYTES = sizeof(double) * 4 * 5 * SVW;      // one buffer of D / g
     static constexpr size_t SV_BYTES = 2 * SV1_BYTES;
     static constexpr size_t VI_BYTES = sizeof(double) * 2 * 4 * 5 * MH;     // row-start column sums (strip 0), 2 buffers
@@ -136,6 +153,24 @@ extern "C" int nsof_debug_xtiming(unsigned long long* out32, int reset)
 #define XT_FLUSH(base)
 #endif
 
+#ifdef NSOF_X_JOBLOG
+// Tuning build only (scripts/build_variant.sh xjl farneback_iterate_x.hip -DNSOF_X_JOBLOG; scripts/x_joblog.py): per job the
+// 100 MHz real-time stamps of its start, of the moment its pipeline is primed (barrier Bb) and of its end, with the CU it ran
+// on -- the per-CU timeline of a launch (dispatch gaps between jobs, start-up cost, chain lag, tail).
+__device__ unsigned long long g_xjob[8192 * 4];
+__device__ unsigned g_xjob_n;
+extern "C" int nsof_debug_xjoblog(unsigned long long* out, unsigned* n, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xjob), sizeof(g_xjob)) != hipSuccess) return -1;
+    if (n && hipMemcpyFromSymbol(n, HIP_SYMBOL(g_xjob_n), sizeof(unsigned)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_xjob_n), &z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 constexpr unsigned X_SPIN_LIMIT = 1u << 21;   // polls of a carry before giving up (seconds): the grid always drains
 
 // ---- producers ------------------------------------------------------------------------------------------------------
@@ -159,19 +194,31 @@ template <int MH>
 __device__ __forceinline__ void x_rows_above(const XRing& ring, const Planes& R0, const Planes& R1, const FlowSrc<false>& F,
                                              int W, int H, int xc, int col)
 {
-    RowIn t;
-    float M0[5];
-    issue_row(t, R0, R1, W, H, xc, 0, F.at(0));
-    matrix_from(t, xc, 0, W, H, M0);
+    // A job's start-up is a chain of memory latencies (flow -> gather address -> gather -> matrix), ~1.5-2 us each under
+    // load: taken one row at a time they cost 22 us per job (3 % of a 1080p strip, 17 % of its 135-row level).  So: the
+    // flow of all m rows first, then the gathers of up to four rows in flight at once.
+    float2 fl[MH];
 #pragma unroll
-    for (int j = 0; j <= MH + 1; j++) ring.put(j, col, M0);   // stream indices -m-1 .. 0
+    for (int i = 0; i < MH; i++) fl[i] = F.at(min(i, H - 1));
+    constexpr int GRP = 4;
 #pragma unroll
-    for (int i = 1; i < MH; i++) {
-        float Mi[5];
-        const int r = min(i, H - 1);
-        issue_row(t, R0, R1, W, H, xc, r, F.at(r));
-        matrix_from(t, xc, r, W, H, Mi);
-        ring.put(i + MH + 1, col, Mi);
+    for (int g0 = 0; g0 < MH; g0 += GRP) {
+        RowIn t[GRP];
+#pragma unroll
+        for (int k = 0; k < GRP; k++)
+            if (g0 + k < MH) issue_row(t[k], R0, R1, W, H, xc, min(g0 + k, H - 1), fl[g0 + k]);
+#pragma unroll
+        for (int k = 0; k < GRP; k++)
+            if (g0 + k < MH) {
+                float Mi[5];
+                matrix_from(t[k], xc, min(g0 + k, H - 1), W, H, Mi);
+                if (g0 + k == 0) {
+#pragma unroll
+                    for (int j = 0; j <= MH + 1; j++) ring.put(j, col, Mi);   // stream indices -m-1 .. 0
+                } else {
+                    ring.put(g0 + k + MH + 1, col, Mi);
+                }
+            }
     }
 }
 
@@ -227,6 +274,53 @@ __device__ __forceinline__ void x_producer_loop(const XRing& ring, const Planes&
     XT_FLUSH(8 + 8 * GP);
 }
 
+// ---- the solves outside the consumers: lane <-> columns lane, lane + 64, lane + 128 of the strip ----------------------------
+// In window t the scanner's g of step t-1 (left half) and of step t-2 (right half) are complete.  A wave takes the sums of its
+// rows [Q0, Q0 + NQ) of all three column blocks into registers first and releases the slots (flag = t + 1), then solves the
+// 2x2 systems and stores the flow: every store instruction writes 64 consecutive vectors of one image row.
+template <int MH, int Q0, int NQ>
+__device__ __forceinline__ void x_solve_rows(const double* sv, volatile lds_int* flag, float2* Fout, size_t fpitch, int W, int H,
+                                             int x0, int nimg, double scale, int lane, int t)
+{
+    using G = XGeom<MH>;
+    constexpr int SVW = G::SVW, NBLK = G::SW / 64;
+    if constexpr (NQ > 0) {
+        double g[NBLK][NQ][5];
+        int us[NBLK];
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            const int col = b * 64 + lane;
+            const int u = t - 1 - (col >= G::SEG0 ? 1 : 0);
+            us[b] = (u >= 0 && u < nimg && x0 + col < W) ? u : -1;
+            const double* p = sv + (u & 1) * (G::SV1_BYTES / sizeof(double)) + col;
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) g[b][q][c] = p[((q + Q0) * 5 + c) * SVW];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the sums are in registers ...
+        if (lane == 0) *flag = t + 1;                           // ... their slots may take the next D
+#ifndef NSOF_X_ABL_SOLVE   // timing-only ablation: no solve at all
+#pragma unroll
+        for (int b = 0; b < NBLK; b++) {
+            if (us[b] < 0) continue;
+            const int x = x0 + b * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int yo = 4 * us[b] + q + Q0;
+                const double g11 = g[b][q][0] * scale, g12 = g[b][q][1] * scale, g22 = g[b][q][2] * scale;
+                const double h1 = g[b][q][3] * scale, h2 = g[b][q][4] * scale;
+                const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
+                const float ox = (float)((g11 * h2 - g12 * h1) * idet), oy = (float)((g22 * h1 - g12 * h2) * idet);
+                if (yo < H) nsof_store_stream2(reinterpret_cast<float*>(Fout + (size_t)yo * fpitch + x), ox, oy);
+            }
+        }
+#endif
+    } else {
+        if (lane == 0) *flag = t + 1;
+    }
+}
+
 // Remainder wave: lane <-> (row r of the step, ring column 192 + c): one row per step and thread.  With time to spare, it
 // is also the strip's I/O wave: it publishes the row-end sums the scanner left in LDS (cb[0][step & 1][20]) to the right
 // neighbour and fetches the left neighbour's (-> cb[1][step & 1][20], a step ahead of the scanner), so that the scanner
@@ -237,7 +331,8 @@ __device__ __forceinline__ void x_producer_loop(const XRing& ring, const Planes&
 template <int MH>
 __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, const Planes& R0, const Planes& R1,
                                                  const FlowSrc<false>& F, int W, int H, int xc, int col, int r, int nimg,
-                                                 gu64* cin, gu64* cout, unsigned epoch, gu32* err, bool xt)
+                                                 gu64* cin, gu64* cout, unsigned epoch, gu32* err, bool xt, const double* sv,
+                                                 volatile lds_int* ioflag, float2* Fout, size_t fpitch, int x0, double scale)
 {
     const int lane = threadIdx.x & 63;
     const bool io = lane < 20;
@@ -245,11 +340,21 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
     // the left neighbour's row-end sums of step s -> cb[1][s & 1]: the loads are issued first (fetch_issue), this thread's
     // row is produced meanwhile, then the tags are checked (fetch_finish; a stale tag means the neighbour is not a full step
     // ahead yet: poll)
+    // The two loads are written as asm and waited for with a COUNTED s_waitcnt: the compiler's own wait for an atomic load
+    // inside this control flow was vmcnt(0), i.e. every step also waited for the row and flow loads this wave had just issued
+    // for two and four steps ahead (a full memory latency, ~1800 clocks per step: harmless while the wave had nothing else to
+    // do, not once it solves).  vmcnt(9): the carry loads are older than the 9 loads x_produce always issues after them
+    // (8 of issue_row + the flow fetch; the asm statements clobber "memory", so none of those moves ahead of them), loads
+    // return in order, so "at most 9 outstanding" means the carries have arrived.
     unsigned long long g0 = 0, g1 = 0;
+    auto carry_load = [&](int s) {
+        const gu64* q = cin + 40 * s + 2 * l;
+        asm volatile("global_load_dwordx2 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %2, off offset:8 sc1"
+                     : "=&v"(g0), "=&v"(g1) : "v"(q) : "memory");
+    };
     auto fetch_issue = [&](int s) {
         if (!cin || !io) return;
-        g0 = __hip_atomic_load(cin + 40 * s + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        g1 = __hip_atomic_load(cin + 40 * s + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        carry_load(s);
     };
     // A wait that runs out (X_SPIN_LIMIT polls, or the launch's error word already set by another strip -- looked at every
     // 256 polls) marks the launch failed and is STICKY: this strip stops polling for the rest of its walk, so a failed
@@ -257,6 +362,7 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
     bool dead = false;
     auto fetch_finish = [&](int s) {
         if (!cin || !io) return;
+        asm volatile("s_waitcnt vmcnt(9)" : "+v"(g0), "+v"(g1) : : "memory");
         for (unsigned spins = 0; !dead; spins++) {
             if (__all((unsigned)(g0 >> 32) == epoch && (unsigned)(g1 >> 32) == epoch)) break;
             if (spins > X_SPIN_LIMIT ||
@@ -266,8 +372,8 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
-            g0 = __hip_atomic_load(cin + 40 * s + 2 * l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            g1 = __hip_atomic_load(cin + 40 * s + 2 * l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            carry_load(s);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0), "+v"(g1) : : "memory");
         }
         cb[40 + (s & 1) * 20 + l] = __hiloint2double((int)(unsigned)g1, (int)(unsigned)g0);
     };
@@ -305,6 +411,9 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
         if (t + 1 < nimg) fetch_issue(t + 1);
         x_produce<MH>(in[TS], fl[TS], ring, R0, R1, F, W, H, xc, col, 4 * (t + 2) + MH + r);
         XT_MARK(0);
+        // its share of the step's 2x2 solves (rows [CQ, CQ + IOQ)) while the carry fetch is in flight
+        x_solve_rows<MH, XGeom<MH>::CQ, XGeom<MH>::IOQ>(sv, ioflag, Fout, fpitch, W, H, x0, nimg, scale, lane, t);
+        XT_MARK(3);
         if (t + 1 < nimg) fetch_finish(t + 1);
         XT_MARK(2);
         XT_BAR();                                                                    // B(t)
@@ -315,13 +424,21 @@ __device__ __forceinline__ void x_remainder_loop(const XRing& ring, double* cb, 
         window(std::integral_constant<int, 1>{}, t + 1);
     }
     publish(nimg - 1);
+    x_solve_rows<MH, XGeom<MH>::CQ, XGeom<MH>::IOQ>(sv, ioflag, Fout, fpitch, W, H, x0, nimg, scale, lane, nimg + 1);   // window nimg + 1: the right half's last step
     XT_FLUSH(12);
 }
 
 // ---- consumers: thread <-> output column j of the strip ----------------------------------------------------------
+// Column sums only (round 4): the 2x2 solves moved to a wave of their own on SIMD 3 (x_solver_loop) -- the instruction mix
+// of a step was 1144 issue units on each of SIMDs 0-2 (a consumer + two producers) against 363 on SIMD 3 (scanner + I/O
+// wave), and the step is bound by vector issue on the fuller SIMDs.  The solver reads g out of the D / g buffers at the start
+// of a window and says so (sflag = window + 1); the consumers overwrite those slots with the next D at the END of their
+// window, after that flag.  The right half of the strip is scanned a window later than the left one, so its threads hold a
+// step's D for one more window: two register sets used alternately (the loop is unrolled by two).
 template <int MH>
-__device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, double* vinit, float2* Fout, size_t fpitch,
-                                                int W, int H, int x0, int j, int nimg, double scale, bool strip0, bool xt)
+__device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, double* vinit, volatile lds_int* sflag, float2* Fout,
+                                                size_t fpitch, int W, int H, int x0, int j, int nimg, double scale, bool strip0,
+                                                bool xt, unsigned xjl_slot = 0)
 {
     using G = XGeom<MH>;
     constexpr int RL = G::RL, SVW = G::SVW, HALO = G::HALO;
@@ -356,16 +473,16 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
     int slot_old = 0;                           // stream index -m-1 -> slot 0
     const int x = x0 + j;
     // The scanner works on the strip's two halves a step apart (segment 1 of step s in the window after segment 0 of step
-    // s), so the threads of the right half publish their D one window late (kept in registers meanwhile) and solve one
-    // window late: lag = 1.
+    // s), so the threads of the right half publish their D one window late (kept in registers meanwhile): lag = 1.
     const int lag = j >= G::SEG0 ? 1 : 0;
 #ifdef NSOF_X_CPRIO
     __builtin_amdgcn_s_setprio(NSOF_X_CPRIO);
 #endif
     XT_DECL(xt && j == 0);
-    double Dreg[4][5];
-    // step s: four more rows enter the windows of this thread's two columns -> Dreg
-    auto column_sums = [&](int s) {
+    double D[2][4][5];   // D[s & 1] = D of step s
+    // step s: four more rows enter the windows of this thread's two columns -> D[P], P = s & 1
+    auto column_sums = [&](auto pc, int s) {
+        constexpr int P = decltype(pc)::value;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float na[5], oa[5], nb[5], ob[5];
@@ -379,7 +496,7 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
                 const float db = nb[c] - ob[c];
                 va[c] += (double)da;
                 vb[c] += (double)db;
-                Dreg[q][c] = va[c] - vb[c];
+                D[P][q][c] = va[c] - vb[c];
             }
             if (vi_thread) {
 #pragma unroll
@@ -389,52 +506,78 @@ __device__ __forceinline__ void x_consumer_loop(const XRing& ring, double* sv, d
             slot_old = slot_old + 1 == RL ? 0 : slot_old + 1;
         }
     };
-    // D of step p (held in Dreg) -> buffer p & 1, into slots this thread has read in this window (own column) or nobody
-    // reads any more
-    auto publish = [&](int p) {
+    // D of step p (in D[P]) -> buffer p & 1
+    auto publish = [&](auto pc, int p) {
+        constexpr int P = decltype(pc)::value;
         if (p < 0 || p >= nimg) return;
         double* svj = sv + (p & 1) * (G::SV1_BYTES / sizeof(double)) + j;
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int c = 0; c < 5; c++) svj[(q * 5 + c) * SVW] = Dreg[q][c];
+            for (int c = 0; c < 5; c++) svj[(q * 5 + c) * SVW] = D[P][q][c];
     };
-    column_sums(0);
-    if (!lag) publish(0);
+    column_sums(std::integral_constant<int, 0>{}, 0);
+    if (!lag) publish(std::integral_constant<int, 0>{}, 0);
     __syncthreads();   // Bb: D(0) of the left half is published, step 1 is in the ring
-    for (int t = 0; t <= nimg + 1; t++) {
-        XT_MARK(1);        // wait at the barrier
-        const int u = t - 1 - lag;   // the step whose g the scanner completed in the last window
-#ifdef NSOF_X_ABL_SOLVE   // timing-only ablation: no solve at all
-        if (false) {
-#else
-        if (u >= 0 && u < nimg && x < W) {
+#ifdef NSOF_X_JOBLOG
+    if (threadIdx.x == 0 && xjl_slot < 8192u) g_xjob[4 * xjl_slot + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-            const double* svj = sv + (u & 1) * (G::SV1_BYTES / sizeof(double)) + j;
+    // window t (P = t & 1): D[P] = D(t), formed a window ago; column_sums(t + 1) -> D[P ^ 1]
+    auto window = [&](auto pc, int t) {
+        constexpr int P = decltype(pc)::value;
+        XT_MARK(1);        // wait at the barrier
+        if constexpr (G::CQ > 0) {   // rows the consumers still solve themselves (own column: read before it is overwritten)
+            const int u = t - 1 - lag;
+            if (u >= 0 && u < nimg && x < W) {
+                const double* svj = sv + (u & 1) * (G::SV1_BYTES / sizeof(double)) + j;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int yo = 4 * u + q;
-                const double g11 = svj[(q * 5 + 0) * SVW] * scale, g12 = svj[(q * 5 + 1) * SVW] * scale;
-                const double g22 = svj[(q * 5 + 2) * SVW] * scale;
-                const double h1 = svj[(q * 5 + 3) * SVW] * scale, h2 = svj[(q * 5 + 4) * SVW] * scale;
-                const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
-                const float ox = (float)((g11 * h2 - g12 * h1) * idet), oy = (float)((g22 * h1 - g12 * h2) * idet);
-                if (yo < H) nsof_store_stream2(reinterpret_cast<float*>(Fout + (size_t)yo * fpitch + x), ox, oy);
+                for (int q = 0; q < G::CQ; q++) {
+                    const int yo = 4 * u + q;
+                    const double g11 = svj[(q * 5 + 0) * SVW] * scale, g12 = svj[(q * 5 + 1) * SVW] * scale;
+                    const double g22 = svj[(q * 5 + 2) * SVW] * scale;
+                    const double h1 = svj[(q * 5 + 3) * SVW] * scale, h2 = svj[(q * 5 + 4) * SVW] * scale;
+                    const double idet = nsof_recip_normal(g11 * g22 - g12 * g12 + 1e-3);
+                    const float ox = (float)((g11 * h2 - g12 * h1) * idet), oy = (float)((g22 * h1 - g12 * h2) * idet);
+                    if (yo < H) nsof_store_stream2(reinterpret_cast<float*>(Fout + (size_t)yo * fpitch + x), ox, oy);
+                }
             }
         }
         XT_MARK(2);        // solve
-        if (t == nimg + 1) break;
-#ifndef NSOF_X_ABL_PUB    // timing-only ablation: no second publish pass in the wave that straddles the segment boundary
-        if (lag) publish(t);                       // right half: D(t), formed a window ago
-#else
-        if (lag && j >= 128) publish(t);
-#endif
-        if (t + 1 < nimg) column_sums(t + 1);
-        if (!lag) publish(t + 1);                  // left half: D(t+1), at once
+        if (t == nimg + 1) return;
+        if (t + 1 < nimg) column_sums(std::integral_constant<int, P ^ 1>{}, t + 1);
+        // the solver wave has taken g(t-1) (left half) / g(t-2) (right half) out of the slots D goes into now; the wait is
+        // bounded like every other (a wave of this workgroup sets the flag; normally long before)
+        for (int spin = 0; (sflag[0] < t + 1 || (G::IOQ > 0 && sflag[1] < t + 1)) && spin < (1 << 22); spin++)
+            __builtin_amdgcn_s_sleep(1);
+        if (lag) publish(std::integral_constant<int, P>{}, t);            // right half: D(t), formed a window ago
+        else publish(std::integral_constant<int, P ^ 1>{}, t + 1);        // left half: D(t+1), at once
         XT_MARK(0);        // column sums
         XT_BAR();          // B(t)
+    };
+    for (int t = 0; t <= nimg + 1; t += 2) {
+        window(std::integral_constant<int, 0>{}, t);
+        if (t + 1 > nimg + 1) break;
+        window(std::integral_constant<int, 1>{}, t + 1);
     }
     XT_FLUSH(0);
+}
+
+// The solver wave (the workgroup's last: SIMD 3, next to the scanner and the I/O wave).
+template <int MH>
+__device__ __forceinline__ void x_solver_loop(const double* sv, volatile lds_int* sflag, float2* Fout, size_t fpitch, int W, int H,
+                                              int x0, int nimg, double scale, int lane, bool xt)
+{
+    using G = XGeom<MH>;
+    __syncthreads();   // Ba
+    __syncthreads();   // Bb
+    XT_DECL(xt && lane == 0);
+    for (int t = 0; t <= nimg + 1; t++) {
+        XT_MARK(1);        // wait at the barrier
+        x_solve_rows<MH, G::CQ + G::IOQ, 4 - G::CQ - G::IOQ>(sv, sflag, Fout, fpitch, W, H, x0, nimg, scale, lane, t);
+        XT_MARK(2);        // read g, solve, store
+        if (t <= nimg) XT_BAR();   // B(t)
+    }
+    XT_FLUSH(20);
 }
 
 // ---- the scanner wave -------------------------------------------------------------------------------------------------
@@ -641,10 +784,23 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
         }
         job[0] = i < share ? (int)((i / (unsigned)nstrips) * 8u + k) : -1;
         job[1] = (int)(i % (unsigned)nstrips);
+        job[2] = job[3] = 0;   // "slots released up to window" flags of the solver wave and of the I/O wave
     }
     __syncthreads();
     const int pair = job[0], strip = job[1];
     if (pair < 0 || pair >= n) return;   // block-uniform
+#ifdef NSOF_X_JOBLOG
+    unsigned xjl_slot = 0xffffffffu;
+    if (tid == 0) {
+        xjl_slot = atomicAdd(&g_xjob_n, 1u);
+        if (xjl_slot < 8192u) {
+            g_xjob[4 * xjl_slot] = __builtin_amdgcn_s_memrealtime();
+            const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+            g_xjob[4 * xjl_slot + 3] = ((unsigned long long)xcc_id() << 48) | ((unsigned long long)hw << 16) |
+                                       ((unsigned long long)(pair & 0xfff) << 4) | (unsigned)(strip & 0xf);
+        }
+    }
+#endif
     size_t fpitch = (size_t)W;
     gu64* cbase;
     if constexpr (HET) {
@@ -680,9 +836,18 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
 #else
     const bool xt = false;
 #endif
+    volatile lds_int* sflag = (volatile lds_int*)(job + 2);
     if (wave < G::NCW) {
         float2* Fout = reinterpret_cast<float2*>(flow_out) + (HET ? 0 : (size_t)pair * plane);
-        x_consumer_loop<MH>(ring, sv, vinit, Fout, fpitch, W, H, x0, tid, nimg, 1. / (block_size * block_size), strip == 0, xt);
+#ifdef NSOF_X_JOBLOG
+        x_consumer_loop<MH>(ring, sv, vinit, sflag, Fout, fpitch, W, H, x0, tid, nimg, 1. / (block_size * block_size), strip == 0, xt, xjl_slot);
+        if (tid == 0 && xjl_slot < 8192u) g_xjob[4 * xjl_slot + 2] = __builtin_amdgcn_s_memrealtime();
+#else
+        x_consumer_loop<MH>(ring, sv, vinit, sflag, Fout, fpitch, W, H, x0, tid, nimg, 1. / (block_size * block_size), strip == 0, xt);
+#endif
+    } else if (wave == G::WAVES - 1) {
+        float2* Fout = reinterpret_cast<float2*>(flow_out) + (HET ? 0 : (size_t)pair * plane);
+        x_solver_loop<MH>(sv, sflag, Fout, fpitch, W, H, x0, nimg, 1. / (block_size * block_size), tid & 63, xt);
     } else if (wave == G::NCW) {
         const int ncols = min(G::SEG0, (W - x0 + 7) & ~7);   // columns of the left segment
         x_scanner_loop<MH>(sv, vinit, cb, strip > 0, nimg, ncols, tid & 63, xt);
@@ -719,7 +884,9 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
             gu64* cin = strip > 0 ? cbase + (size_t)(strip - 1) * per_strip : nullptr;
             // NSOF_OPT_DEBUG_FAULT bit 0 (test hook): strip 0 of item 0 keeps its carries to itself
             gu64* cout = x0 + SW < W && !((fault & 1) && pair == 0 && strip == 0) ? cbase + (size_t)strip * per_strip : nullptr;
-            x_remainder_loop<MH>(ring, cb, R0, R1, F, W, H, xc, col, r, nimg, cin, cout, epoch, (gu32*)err, xt);
+            float2* Fout = reinterpret_cast<float2*>(flow_out) + (HET ? 0 : (size_t)pair * plane);
+            x_remainder_loop<MH>(ring, cb, R0, R1, F, W, H, xc, col, r, nimg, cin, cout, epoch, (gu32*)err, xt, sv, sflag + 1, Fout, fpitch,
+                                 x0, 1. / (block_size * block_size));
         } else {
             const int col = blk * 64 + lane;
             const int xc = clampi(x0 - MH - 1 + col, 0, W - 1);

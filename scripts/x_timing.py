@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a step of k_iterate_x goes: constant-clock ticks (10 ns) that one wave of each role of the workgroup with job
+"""Where a step of k_iterate_x goes: s_memtime ticks (shader clocks on gfx950: scripts/lr_timing.py measured 23.3 per 10 ns) that one wave of each role of the workgroup with job
 (pair 0, strip 1) spends working and waiting.  Needs the tuning build:
     scripts/build_variant.sh xt farneback_iterate_x.hip -DNSOF_X_TIMING
     NSOF_LIB=.../nsof/libnsof_xt.so python scripts/x_timing.py [--winsize 15] [--pairs 64]"""
@@ -50,14 +50,15 @@ steps = (h + 3) // 4 + 1
 names = ["consumer: column sums", "consumer: wait at barrier", "consumer: solve", "-",
          "scanner: wait for carry", "scanner: scan", "scanner: wait at barrier", "-",
          "producer rows 0,1: rows", "producer rows 0,1: wait at barrier", "-", "-",
-         "remainder wave: publish + row", "remainder wave: wait at barrier", "remainder wave: fetch carry", "-",
-         "producer rows 2,3: rows", "producer rows 2,3: wait at barrier", "-", "-"]
+         "remainder wave: publish + row", "remainder wave: wait at barrier", "remainder wave: fetch carry", "remainder wave: solve",
+         "producer rows 2,3: rows", "producer rows 2,3: wait at barrier", "-", "-",
+         "-", "solver: wait at barrier", "solver: read + solve + store", "-"]
 print(f"winsize {a.winsize}, {steps} steps, launch {ms * 1e3 / cnt:.1f} us; 10-ns ticks per step")
 for k, nm in enumerate(names):
     print(f"  {nm:32s} {out[k] / steps:9.1f}")
 for role, sl in (("consumer", range(0, 4)), ("scanner", range(4, 8)), ("producer 0,1", range(8, 12)), ("remainder", range(12, 16)),
-                 ("producer 2,3", range(16, 20))):
+                 ("producer 2,3", range(16, 20)), ("solver", range(20, 24))):
     print(f"  {role} total {sum(out[k] for k in sl) / steps:9.1f}")
 print("  barrier wait per wave (0-2 consumers, 3 scanner, 4-6 rows 0,1, 7 remainder, 8-10 rows 2,3):")
-print("   ", " ".join(f"{out[32 + k] / steps:7.0f}" for k in range(11)))
+print("   ", " ".join(f"{out[32 + k] / steps:7.0f}" for k in range(12)))
 ctx.close()
