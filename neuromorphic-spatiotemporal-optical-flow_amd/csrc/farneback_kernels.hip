@@ -12,6 +12,8 @@
 // loads.  M planar [n][5][h][w] f32 (unfused path only).  Flow [n][h][w][2].
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "nsof_internal.h"
 
 // This translation unit is compiled twice.  The regular object forms the float Gaussian blur and the bilinear resamples
@@ -547,43 +549,57 @@ __global__ __launch_bounds__(256) void k_prep_direct(const uint8_t* __restrict__
 // source row ONCE: 1.7 instead of 4 row evaluations per destination pixel at level 1, 4.6 instead of 10 at level 3.  The
 // advance loop is wave-uniform (source rows depend on the destination row only).  Same helper functions and operation
 // order as the direct kernel -> bit-identical output.  Parameter sets B / C (pyr_scale 0.6): levels 1 and 2 (3 / 5 taps).
-template <int KS>
-__global__ __launch_bounds__(256) void k_prep_walk(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
-                                                    ptrdiff_t img_stride, int W, int H, int wk, int hk, double scale_x,
-                                                    double scale_y, int seg_rows, nsof_blur_taps t, float* __restrict__ out)
+// Round 4: the walk is written for the scalar unit.  Everything that depends on the destination ROW only -- the source
+// rows of its window, "has the window's last row entered", the vertical blend weight -- is wave-uniform and now lives in
+// SGPRs (readfirstlane), so the loop's control flow is scalar branches instead of exec-mask bookkeeping; and whether a
+// lane may take the unaligned-dword fast path (its KS + 1 bytes lie inside the image) is decided once per WAVE: only the
+// waves that touch the left / right image border run the per-byte reflecting loads.  The first version spent ~240
+// instructions per source row, most of them mask handling around the per-lane fast / slow choice (ISA: 54 s_cbranch_execz,
+// 53 s_and_saveexec, 47 v_cndmask, 24 global_load_ubyte per 4 source rows), where the arithmetic needs ~20.
+template <int U, int N, class F>
+__device__ __forceinline__ void prep_static_slots(F& f)
+{
+    if constexpr (U < N) {
+        if (f(std::integral_constant<int, U>{})) prep_static_slots<U + 1, N>(f);
+    }
+}
+
+template <int KS, bool WFAST>
+__device__ __forceinline__ void prep_walk_body(const uint8_t* __restrict__ img, ptrdiff_t row_stride, int W, int H, int wk, int hk,
+                                               double scale_y, int dy0, int dy_end, int dx, bool live, int c0, int c1, bool fast,
+                                               float a1, const nsof_blur_taps& t, float* __restrict__ dst)
 {
     constexpr int R = KS / 2, NB = KS + 1, ND = (NB + 3) / 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int dy0 = (blockIdx.y * 4 + wave) * seg_rows;
-    if (dy0 >= hk) return;                                        // wave-uniform
-    const int dxr = blockIdx.x * 64 + lane;
-    const bool live = dxr < wk;
-    const int dx = live ? dxr : wk - 1;
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
-    float* dst = out + (size_t)blockIdx.z * wk * hk;
-    int sx;
-    float a1;
-    lin_coord_x(dx, scale_x, W, sx, a1);
     const float a0 = 1.f - a1;
-    const int c0 = sx, c1 = min(sx + 1, W - 1);
-    const bool fast = c0 - R >= 0 && c0 - R + 4 * ND <= W && c1 == c0 + 1;
     auto tk = [&](int j) { return t.k[j]; };   // j is a compile-time constant after unrolling
-    // row-filtered values of source row rr (any integer: reflected) at columns c0 and c1
-    auto hrow = [&](int rr, float& h0, float& h1) {
+    const unsigned coff = (unsigned)(c0 - R);    // byte offset of this lane's window in a source row (fast lanes)
+    // the KS + 1 bytes of source row rr (wave-uniform, any integer: reflected) around this lane's two columns, as raw dwords
+    auto load_row = [&](int rr, unsigned (&raw)[ND]) {
+        const uint8_t* rowp = img + (ptrdiff_t)reflect101(rr, H) * row_stride;   // scalar
+#pragma unroll
+        for (int d = 0; d < ND; d++) __builtin_memcpy(&raw[d], rowp + coff + 4 * d, 4);   // unaligned dword loads
+    };
+    // row-filtered values at columns c0 and c1 from those bytes
+    auto filt_row = [&](const unsigned (&raw)[ND], float& h0, float& h1) {
+        float b[NB];
+#pragma unroll
+        for (int d = 0; d < ND; d++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (4 * d + e < NB) b[4 * d + e] = (float)((raw[d] >> (8 * e)) & 0xffu);
+        h0 = row_filter<KS>(tk, KS, R, [&](int c) { return b[c]; });
+        h1 = row_filter<KS>(tk, KS, R + 1, [&](int c) { return b[c]; });
+    };
+    // border waves: per lane, per byte with BORDER_REFLECT_101 where the window leaves the image
+    auto hrow_edge = [&](int rr, float& h0, float& h1) {
         const uint8_t* rowp = img + (ptrdiff_t)reflect101(rr, H) * row_stride;
-        float b[NB], bb[NB];
         if (fast) {
+            unsigned raw[ND];
 #pragma unroll
-            for (int d = 0; d < ND; d++) {
-                unsigned v;
-                __builtin_memcpy(&v, rowp + (c0 - R) + 4 * d, 4);   // unaligned dword load
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (4 * d + e < NB) b[4 * d + e] = (float)((v >> (8 * e)) & 0xffu);
-            }
-            h0 = row_filter<KS>(tk, KS, R, [&](int c) { return b[c]; });
-            h1 = row_filter<KS>(tk, KS, R + 1, [&](int c) { return b[c]; });
+            for (int d = 0; d < ND; d++) __builtin_memcpy(&raw[d], rowp + coff + 4 * d, 4);
+            filt_row(raw, h0, h1);
         } else {
+            float b[NB], bb[NB];
 #pragma unroll
             for (int j = 0; j < KS; j++) {
                 b[j] = (float)rowp[reflect101(c0 - R + j, W)];
@@ -593,26 +609,47 @@ __global__ __launch_bounds__(256) void k_prep_walk(const uint8_t* __restrict__ s
             h1 = row_filter<KS>(tk, KS, R, [&](int c) { return bb[c]; });
         }
     };
+    // destination row dy -> its two source rows and the vertical weight, all wave-uniform (SGPRs)
+    auto row_coord = [&](int dy, int& r0, int& r1, float& b1) {
+        int sy;
+        float bv;
+        lin_coord_y(dy, scale_y, sy, bv);
+        sy = __builtin_amdgcn_readfirstlane(sy);
+        b1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bv)));
+        r0 = clampi(sy, 0, H - 1);
+        r1 = clampi(sy + 1, 0, H - 1);
+    };
     // The row-filtered pairs of the KS + 1 newest source rows live in a register ring with STATIC slots: source rows are
     // taken strictly in order, row rstart + i into slot i % NB (the walk is unrolled NB times), and a destination row is
     // emitted when the last row of its window, r0 + R + 1, has just entered -- its window rows then sit at the slots
     // (u + 1 + q) % NB, q = 0..KS, known at compile time.  (Windows of consecutive destination rows overlap -- the launcher
     // takes this kernel only while a destination step is shorter than the ring -- so no source row is filtered in vain.)
     float H0[NB], H1[NB];
-    const int dy_end = min(dy0 + seg_rows, hk);
-    int dy = dy0, sy;
+    int dy = dy0, r0, r1;
     float b1;
-    lin_coord_y(dy, scale_y, sy, b1);
-    int r0 = clampi(sy, 0, H - 1), r1 = clampi(sy + 1, 0, H - 1);
+    row_coord(dy, r0, r1, b1);
     const int rstart = r0 - R;
     int last = r0 - R + KS;                                        // the source row that completes the window of dy
-    for (int rb = 0; dy < dy_end && rb <= H + 2 * NB; rb += NB) {   // (bounded: at most H + KS + 1 source rows are walked)
+    // (interior waves) the raw bytes of the NEXT block of KS + 1 source rows are requested before this block is filtered:
+    // a wave then has a block of loads in flight instead of waiting for every row's load on its own
+    unsigned cur[NB][ND], nxt[NB][ND];
+    if constexpr (WFAST) {
 #pragma unroll
-        for (int u = 0; u < NB; u++) {
-            if (dy >= dy_end) break;                               // wave-uniform
+        for (int u = 0; u < NB; u++) load_row(rstart + u, cur[u]);
+    }
+    for (int rb = 0; dy < dy_end && rb <= H + 2 * NB; rb += NB) {   // (bounded: at most H + KS + 1 source rows are walked)
+        if constexpr (WFAST) {
+#pragma unroll
+            for (int u = 0; u < NB; u++) load_row(rstart + rb + NB + u, nxt[u]);   // rows beyond the segment: reflected, unused
+        }
+        // (expanded at compile time: with 10 slots a `#pragma unroll` loop stayed rolled and indexed the ring dynamically)
+        auto slot = [&](auto uc) -> bool {
+            constexpr int u = decltype(uc)::value;
+            if (dy >= dy_end) return false;                        // scalar
             const int r = rstart + rb + u;
-            hrow(r, H0[u], H1[u]);
-            if (r == last) {                                       // wave-uniform
+            if constexpr (WFAST) filt_row(cur[u], H0[u], H1[u]);
+            else hrow_edge(r, H0[u], H1[u]);
+            if (r == last) {                                       // scalar
                 const float b0 = 1.f - b1;
                 const float B00 = col_filter<KS>(tk, KS, R, [&](int q) { return H0[(u + 1 + q) % NB]; });
                 const float B01 = col_filter<KS>(tk, KS, R, [&](int q) { return H1[(u + 1 + q) % NB]; });
@@ -626,14 +663,46 @@ __global__ __launch_bounds__(256) void k_prep_walk(const uint8_t* __restrict__ s
                 if (live) __builtin_nontemporal_store(NSOF_MADD(t0, b0, t1 * b1), dst + (size_t)dy * wk + dx);
                 dy++;
                 if (dy < dy_end) {
-                    lin_coord_y(dy, scale_y, sy, b1);
-                    r0 = clampi(sy, 0, H - 1);
-                    r1 = clampi(sy + 1, 0, H - 1);
+                    row_coord(dy, r0, r1, b1);
                     last = r0 - R + KS;
                 }
             }
+            return true;
+        };
+        prep_static_slots<0, NB>(slot);
+        if constexpr (WFAST) {
+#pragma unroll
+            for (int u = 0; u < NB; u++)
+#pragma unroll
+                for (int d = 0; d < ND; d++) cur[u][d] = nxt[u][d];
         }
     }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void k_prep_walk(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                    ptrdiff_t img_stride, int W, int H, int wk, int hk, double scale_x,
+                                                    double scale_y, int seg_rows, nsof_blur_taps t, float* __restrict__ out)
+{
+    constexpr int R = KS / 2, NB = KS + 1, ND = (NB + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dy0 = (blockIdx.y * 4 + wave) * seg_rows;
+    if (dy0 >= hk) return;                                        // wave-uniform
+    const int dy_end = min(dy0 + seg_rows, hk);
+    const int dxr = blockIdx.x * 64 + lane;
+    const bool live = dxr < wk;
+    const int dx = live ? dxr : wk - 1;
+    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
+    float* dst = out + (size_t)blockIdx.z * wk * hk;
+    int sx;
+    float a1;
+    lin_coord_x(dx, scale_x, W, sx, a1);
+    const int c0 = sx, c1 = min(sx + 1, W - 1);
+    const bool fast = c0 - R >= 0 && c0 - R + 4 * ND <= W && c1 == c0 + 1;
+    if (__all(fast))
+        prep_walk_body<KS, true>(img, row_stride, W, H, wk, hk, scale_y, dy0, dy_end, dx, live, c0, c1, true, a1, t, dst);
+    else
+        prep_walk_body<KS, false>(img, row_stride, W, H, wk, hk, scale_y, dy0, dy_end, dx, live, c0, c1, fast, a1, t, dst);
 }
 
 // Resampled level, two passes (kernel sizes 9 and 19: levels 2 and 3 of the reference's parameter sets).
@@ -1725,12 +1794,12 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
             }
 #undef NSOF_DECIM
         } else if (scale_x >= 1.0 && scale_y >= 1.0 && scale_y < taps.ksize &&
-                   (taps.ksize == 3 || taps.ksize == 5 || (taps.ksize == 9 && getenv("NSOF_PREP_WALK9") != nullptr)) &&
-                   getenv("NSOF_PREP_NOWALK") == nullptr) {
+                   (taps.ksize == 3 || taps.ksize == 5 || taps.ksize == 9)) {
             // measured per 128-image launch at 1080p, pyr_scale 0.6: level 1 (3 taps) 637 -> 334 us, level 2 (5 taps) 403 ->
-            // 266 us against the direct kernel (static-slot ring: 367 / 322 us with a shifting ring); with 9 taps (level 3:
-            // 415 x 233 outputs, 4.6 source rows per destination row) the walk still LOSES to the tiled kernel (624 vs 415 us):
-            // opt-in there for A/B runs (NSOF_PREP_WALK9)
+            // 266 us against the direct kernel (static-slot ring: 367 / 322 us with a shifting ring).  Round 4 (scalar
+            // control flow, per-wave fast path, a block of loads in flight; per 256 images): 3 taps 658 -> 497 us, 5 taps
+            // 519 -> 490 us, and with 9 taps (level 3: 415 x 233 outputs, 4.6 source rows per destination row) the walk
+            // now beats the tiled kernel too (762 vs 813 us), which it lost to before (624 vs 415 us per 128)
             // segments of destination rows: long enough that the KS+1 rows of warm-up are a few per cent, short enough
             // that a small batch still has a few thousand waves
             int seg_rows = 32;
