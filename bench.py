@@ -117,6 +117,10 @@ def main():
                          "compute (nsof.dist.run_sharded_overlapped); printed as 'io_gather' next to the headline")
     ap.add_argument("--io-timeout", type=float, default=240.0,
                     help="seconds after which the scatter/compute/gather leg is abandoned (the headline line is printed regardless)")
+    ap.add_argument("--sharded-legs", action="store_true",
+                    help="run the two N > 1 legs (config5_sharded, config4_sharded) at N = 1 as well (they are on by default for N > 1)")
+    ap.add_argument("--config4-pairs", type=int, default=0,
+                    help="frame pairs per dataset in the config4_sharded leg (0 = every pair the reference's loops walk: 360 pairs, 645 calls)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the joined events -> accumulator -> flow leg (BASELINE config 5) and its accumulator record")
     ap.add_argument("--no-fast-leg", action="store_true",
@@ -273,38 +277,51 @@ def main():
                                                       f"{ent['traffic_over_algorithmic']} from profiles/hbm_traffic.json "
                                                       "(rocprofv3 --pmc passes over this bench's own launches, all "
                                                       "levels: scripts/prof_traffic_bench.sh, see its _doc)")
-    # The scatter / compute / gather leg (every rank takes part).  The headline above is already measured: a watchdog makes
-    # sure it is printed even if this leg -- point-to-point RCCL traffic that a one-GPU box cannot rehearse -- hangs or
-    # fails on some rank (the line then carries the error instead of the leg's numbers).
-    if (args.io == "gather" or (args.io == "auto" and world > 1)) and args.mode == "pairs":
-        import threading
+    # The legs every rank takes part in: scatter / compute / gather (rank 0 owns the pairs), BASELINE config 5 sharded
+    # (accumulator row bands -> all-gather of the surface frames -> sharded pairs) and BASELINE config 4 sharded (the five
+    # datasets' call list dealt round-robin).  The headline above is already measured: a watchdog makes sure it is printed
+    # even if one of them -- RCCL traffic that a one-GPU box cannot rehearse -- hangs or fails on some rank (the line then
+    # carries the error in place of that leg's numbers, and every rank leaves with exit code 4).
+    import threading
 
-        # what the watchdog prints: a private copy of the measured headline (the main thread keeps adding to `out`)
-        headline = json.loads(json.dumps(out)) if rank == 0 else None
+    def arm_watchdog(leg):
+        # what the watchdog prints: a private copy of what has been measured so far (the main thread keeps adding to `out`)
+        snapshot = json.loads(json.dumps(out)) if rank == 0 else None
 
         def emergency():
-            # the leg hung (or timed out) on this rank: rank 0 still prints the headline it has measured, with the error in
-            # place of the leg's numbers, and EVERY rank leaves with exit code 4 so that the hang is visible in the run's
-            # status, not only in the JSON
             with state["lock"]:
                 if rank == 0 and not state["printed"]:
-                    headline["io_gather"] = {"error": f"the scatter/compute/gather leg did not finish within {args.io_timeout} s",
-                                             "exit_code": 4}
-                    os.write(real_stdout, (json.dumps(headline) + "\n").encode())
+                    snapshot[leg] = {"error": f"the {leg} leg did not finish within {args.io_timeout} s", "exit_code": 4}
+                    os.write(real_stdout, (json.dumps(snapshot) + "\n").encode())
                     state["printed"] = True
                 os._exit(4)
 
-        wd = threading.Timer(args.io_timeout, emergency)
-        wd.daemon = True
-        wd.start()
+        t = threading.Timer(args.io_timeout, emergency)
+        t.daemon = True
+        t.start()
+        return t
+
+    def run_leg(key, fn):
+        nonlocal wd
+        if wd is not None:
+            wd.cancel()
+        wd = arm_watchdog(key)
         try:
-            io_rec = io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w, prevs, nexts)
+            rec = fn()
         except Exception as e:   # noqa: BLE001 -- reported in the line; peers stuck in a collective are ended by their watchdogs
-            io_rec = {"error": f"{type(e).__name__}: {e}"[:400]}
+            rec = {"error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1:
-            wd.cancel()           # N > 1: stays armed until the process group is torn down
-        if rank == 0 and io_rec:
-            out["io_gather"] = io_rec
+            wd.cancel()           # N > 1: stays armed until the next leg / the process group is torn down
+        if rank == 0 and rec:
+            out[key] = rec
+
+    if (args.io == "gather" or (args.io == "auto" and world > 1)) and args.mode == "pairs":
+        run_leg("io_gather", lambda: io_gather_leg(nsof, torch, dist if use_dist else None, ctx, p, dev, rank, world, n, h, w,
+                                                   prevs, nexts))
+    if (world > 1 or args.sharded_legs) and args.mode == "pairs":
+        run_leg("config5_sharded", lambda: config5_sharded_leg(nsof, torch, dist if use_dist else None, ctx, dev, rank, world, rehearsal))
+        run_leg("config4_sharded", lambda: config4_sharded_leg(nsof, torch, dist if use_dist else None, ctx, dev, rank, world, rehearsal,
+                                                               args.config4_pairs))
     if rank == 0:
         if world == 1 and prof and args.mode == "pairs" and not args.no_fast_leg:
             out.update(fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg, roof_of=roof,
@@ -329,7 +346,7 @@ def main():
         if world == 1 and args.cpu_sample > 0 and args.mode == "pairs":
             out.update(cpu_leg(nsof, p, prevs, nexts, flow, min(args.cpu_sample, n)))
         # one verdict over every parity record of the line: the default mode must stay within 1e-4 everywhere
-        for key in ("real_frames", "config5", "config3"):
+        for key in ("real_frames", "config5", "config3", "config5_sharded"):
             if isinstance(out.get(key), dict) and out[key].get("parity_ok") is False:
                 out["parity_ok"] = False
         sys.stdout.flush()
@@ -657,6 +674,129 @@ def config5_leg(nsof, torch, local_rank):
                           "stream_seconds_per_wall_second": round((n_sl / 1000.0) / (tm["accumulator_s"] + tm["flow_s"]), 2),
                           "flow_finite": finite}
     return out
+
+
+def _max_over_ranks(torch, dist, value, dev, rehearsal):
+    if dist is None or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if (rehearsal or dist.get_backend() == "gloo") else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _gather_objects(dist, obj, world):
+    if dist is None or world == 1:
+        return [obj]
+    outs = [None] * world
+    dist.all_gather_object(outs, obj)
+    return outs
+
+
+def config5_sharded_leg(nsof, torch, dist, ctx, dev, rank, world, rehearsal):
+    """BASELINE config 5 over the ranks of the job (BASELINE.json quotes it on 8 MI355X): the synthetic 3840x2160 stream @
+    1 M events/s -> accumulator ROW BANDS (every rank filters the replicated stream to its rows, global slice grid) ->
+    ALL-GATHER of the 8-bit surface frames (the pipeline's one exchange; RCCL over xGMI) -> the pairs of consecutive
+    frames sharded in contiguous chunks through nsof_farneback_u8_sequence_dev
+    (/root/reference/eventsim/event_mem_sim.py:164-228 -> /root/reference/optical_flow_seg.py:203).  Records per-stage
+    time (max over ranks), all-gather bytes and rate, stream-seconds per wall-second, and on rank 0 the first pair
+    against the CPU oracle chain.  UNMEASURED on real multi-GPU hardware by the builder (one-GPU boxes): the numbers of
+    the driver's node are the first."""
+    import numpy as np
+    from nsof import pipeline, synth
+    from nsof.farneback import PARAMS_A
+    from oracle import oracle as O  # noqa: N812
+    H, W, every = 2160, 3840, 33  # noqa: N806
+    x, y, p, t = synth.make_event_stream_4k()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    st = {}
+    pipeline.events_to_flow_sequence_sharded(x, y, p, t, (H, W), snapshot_every=every, ctx=ctx)   # warm-up (workspaces, RCCL channels)
+    barrier()
+    t0 = time.perf_counter()
+    (lo, hi), frames, flows = pipeline.events_to_flow_sequence_sharded(x, y, p, t, (H, W), snapshot_every=every, ctx=ctx, stats=st)
+    barrier()
+    wall = _max_over_ranks(torch, dist, time.perf_counter() - t0, dev, rehearsal)
+    per_rank = _gather_objects(dist, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in st.items()}, world)
+    finite = bool(torch.isfinite(flows).all().item()) if flows is not None else True
+    n_fr = st["frames"]
+    rec = None
+    if rank == 0:
+        ag_s = max(r["allgather_s"] for r in per_rank)
+        ag_bytes = per_rank[0]["allgather_bytes_received"]
+        rec = {"workload": f"events -> accumulator row bands -> all-gather of {n_fr} surface frames -> sharded pairs, Farneback A at "
+                           f"{W}x{H}, {world} rank(s)",
+               "backend": (st["backend"] or "none") + (" (RCCL)" if st["backend"] == "nccl" else ""), "world_size": world,
+               "hardware_note": "rehearsal: ranks share one GPU, gloo collectives -- not a measurement" if rehearsal else
+                                ("one rank: nothing is exchanged" if world == 1 else "measured on this node"),
+               "surface_frames": n_fr, "slices": n_fr * every, "wall_s": round(wall, 4),
+               "stream_seconds_per_wall_second": round(n_fr * every / 1000.0 / wall, 2),
+               "bands_ms_max": round(max(r["bands_s"] for r in per_rank) * 1e3, 2),
+               "allgather_ms_max": round(ag_s * 1e3, 2), "allgather_bytes_received_per_rank": ag_bytes,
+               "allgather_GBps_per_rank": round(ag_bytes / ag_s / 1e9, 2) if ag_bytes and ag_s > 0 else None,
+               "flow_ms_max": round(max(r["flow_s"] for r in per_rank) * 1e3, 2),
+               "pairs_per_rank": [r["pairs"][1] - r["pairs"][0] for r in per_rank],
+               "band_rows_per_rank": [r["band_rows"] for r in per_rank], "flow_finite": finite}
+        # parity of rank 0's first pair: accumulator oracle (33 / 66 slices) -> uint8(255 w) -> Farneback oracle
+        pa = [getattr(PARAMS_A, kk) for kk in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+        _, _, _, usable = O.host_cpu()
+        nt = max(1, min(usable, 16) // max(1, min(world, 8)))   # the ranks of one host share its cores
+        _, w1 = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=every, n_threads=nt)
+        _, w2 = O.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, 0.0, n_slices=2 * every, n_threads=nt)
+        f1, f2 = (np.float32(255.0) * w1).astype(np.uint8), (np.float32(255.0) * w2).astype(np.uint8)
+        gfr = frames[:2].cpu().numpy()
+        frames_equal = bool(np.array_equal(gfr[0], f1) and np.array_equal(gfr[1], f2))
+        d = float(np.abs(flows[0].cpu().numpy() - O.farneback(f1, f2, *pa)).max()) if hi > lo else None
+        rec["first_pair_vs_oracle_chain"] = {"surface_frames_equal": frames_equal, "max_abs_epe_vs_oracle": d,
+                                             "oracle": "oracle/accum_ref.c -> uint8(255 w) -> oracle/farneback_ref.c"}
+        rec["parity_ok"] = bool(frames_equal and (d is None or d < 1e-4))
+    barrier()
+    return rec
+
+
+def config4_sharded_leg(nsof, torch, dist, ctx, dev, rank, world, rehearsal, pairs_per_dataset=0):
+    """BASELINE config 4 over the ranks of the job: every flow call of the reference's evaluation loops over grasp +
+    autodriving + uav + uavnew2 + tabletennis (gated ROI calls + full-frame calls, each dataset's Parameters.txt:
+    /root/reference/data/*/Parameters.txt:1-26, /root/reference/optical_flow_seg.py:390-496; gating rectangles from the
+    reference's .mat stacks, frames synthetic at the real sizes) dealt ROUND-ROBIN over the ranks (nsof.workload.shard_calls:
+    independent calls, no data-path collective); each rank runs its share as work lists, host memory to host memory.
+    Whole-job calls/s = calls / max-over-ranks time.  UNMEASURED on real multi-GPU hardware by the builder."""
+    import numpy as np
+    from nsof import workload as wl
+    with np.load(os.path.join(ROOT, "tests", "golden", "gating_stacks.npz")) as z:
+        stacks = {k: z[k] for k in z.files}
+    t0 = time.perf_counter()
+    calls, _ = wl.mixed_workload(stacks, pairs_per_dataset=pairs_per_dataset or None)
+    t_build = time.perf_counter() - t0
+    mine = wl.shard_calls(calls, rank, world)
+    wl.run_calls(mine[:8], ctx=ctx)                               # warm-up (workspace, pinned staging)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    wl.run_calls(mine, ctx=ctx)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    wall = _max_over_ranks(torch, dist, dt, dev, rehearsal)
+    chk = float(sum(float(np.abs(c.flow[::7, ::7]).sum()) for c in mine[::5]))
+    per_rank = _gather_objects(dist, {"calls": len(mine), "megapixels": round(sum(c.prev.size for c in mine) / 1e6, 1),
+                                      "seconds": round(dt, 4), "flow_checksum": chk,
+                                      "finite": bool(all(np.isfinite(c.flow).all() for c in mine[::5]))}, world)
+    if rank != 0:
+        return None
+    mpx = sum(c.prev.size for c in calls) / 1e6
+    backend = dist.get_backend() if dist is not None else "none"
+    return {"workload": "config 4: grasp+autodriving+uav+uavnew2+tabletennis, gated ROI + full-frame calls, dealt round-robin",
+            "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": world,
+            "hardware_note": "rehearsal: ranks share one GPU, gloo collectives -- not a measurement" if rehearsal else
+                             ("one rank" if world == 1 else "measured on this node"),
+            "calls": len(calls), "roi_calls": sum(c.kind == "roi" for c in calls), "megapixels": round(mpx, 1),
+            "pairs_per_dataset": pairs_per_dataset or "all", "build_workload_s": round(t_build, 2),
+            "wall_s_max_over_ranks": round(wall, 4), "calls_per_s": round(len(calls) / wall, 1), "mpx_per_s": round(mpx / wall, 1),
+            "per_rank": per_rank, "flow_finite": bool(all(r["finite"] for r in per_rank))}
 
 
 def io_gather_leg(nsof, torch, dist, ctx, p, dev, rank, world, n, h, w, prevs, nexts, chunk=32):

@@ -273,6 +273,12 @@ int nsof_accum_step_events(nsof_accum* acc, const int16_t* x, const int16_t* y, 
 int nsof_accum_set_events(nsof_accum* acc, const int16_t* x, const int16_t* y, const int8_t* p,
                           const int64_t* t, const int64_t* slice_bounds, int64_t n_slices);
 int nsof_accum_run(nsof_accum* acc, int64_t first_slice, int64_t n_slices, int64_t snap_every);
+/* Scheme 2 only (a no-op for scheme 1): replace the per-slice timestamps nsof_accum_set_events derived from the staged
+ * events -- the first event's time (refractory test) and the last event's (next_ok = t_last + 800 us),
+ * event_mem_sim.py:243-267 -- by those of the WHOLE stream's slices.  For an accumulator that holds a row band of the
+ * sensor and was staged with the band's events only: its state then equals the band's rows of the unsharded run
+ * (SURVEY.md section 8e).  n_slices must equal the staged count; call between set_events and run. */
+int nsof_accum_set_slice_times(nsof_accum* acc, const int64_t* t_first, const int64_t* t_last, int64_t n_slices);
 /* The current surface as an 8-bit frame on the DEVICE, d_out uint8 [H][row_stride]; asynchronous on the context's
  * stream.  mode NSOF_SURFACE_CURRENT: g = uint8(clip(-3366/log10(I) - 306, 0, 255)), I = 1/R, R = resistance_exp(w) --
  * the reference's map from device current to the gating image (optical_flow_seg.py:426-431) applied per pixel

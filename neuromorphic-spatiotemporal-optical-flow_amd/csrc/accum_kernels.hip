@@ -831,6 +831,32 @@ static int accum_stage(nsof_accum* a, const int16_t* x, const int16_t* y, const 
     return NSOF_OK;
 }
 
+// Scheme 2 reads two timestamps per slice -- its first event's (the refractory test, event_mem_sim.py:243,253,265) and
+// its last event's (+ REFRACTORY_US -> next_ok, :246,256,267) -- and they belong to the slice of the WHOLE stream.  A
+// row band (nsof.dist.simulate_banded) stages only its own events, whose first / last differ: the caller hands the
+// global table over, and the band's state then equals its rows of the unsharded run.
+extern "C" int nsof_accum_set_slice_times(nsof_accum* a, const int64_t* t_first, const int64_t* t_last, int64_t n_slices)
+{
+    if (!a) return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    if (!t_first || !t_last || n_slices != (int64_t)a->h_tfirst.size())
+        return nsof_set_error(ctx, NSOF_EINVAL, "set_slice_times: %lld slices given, %zu staged", (long long)n_slices, a->h_tfirst.size());
+    if (a->scheme != 2) return NSOF_OK;   // scheme 1 reads no timestamps
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    for (int64_t s = 0; s < n_slices; s++) {
+        a->h_tfirst[s] = t_first[s];
+        a->h_tnext[s] = t_last[s] + REFRACTORY_US;
+    }
+    if (n_slices > 0 && a->d_slices) {
+        std::vector<SliceRec> recs((size_t)n_slices);
+        for (int64_t s = 0; s < n_slices; s++)
+            recs[s] = SliceRec{a->h_rel[s], a->h_rel[s + 1] - a->h_rel[s], a->h_tfirst[s], a->h_tnext[s]};
+        NSOF_HIP(ctx, hipMemcpyAsync(a->d_slices, recs.data(), recs.size() * sizeof(SliceRec), hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return NSOF_OK;
+}
+
 // Advance over staged slices [s_begin, s_begin + n_slices).
 static int accum_surface(nsof_accum* a, int which, const SurfOut& so)
 {

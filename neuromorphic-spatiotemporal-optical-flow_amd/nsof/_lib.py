@@ -72,6 +72,7 @@ SIGNATURES = {
     "nsof_accum_reset": (_i, [_vp]),
     "nsof_accum_step_events": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64]),
     "nsof_accum_set_events": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+    "nsof_accum_set_slice_times": (_i, [_vp, _vp, _vp, _i64]),
     "nsof_accum_run": (_i, [_vp, _i64, _i64, _i64]),
     "nsof_accum_surface_u8_dev": (_i, [_vp, _i, _i, _vp, _pd]),
     "nsof_accum_run_surface": (_i, [_vp, _i64, _i64, _i, _i, _vp, _pd]),

@@ -183,6 +183,16 @@ class Accumulator:
                                                            t.ctypes.data, bounds.ctypes.data, bounds.size - 1),
                        "accum_set_events")
 
+    def set_slice_times(self, t_first, t_last):
+        """Scheme 2 on a row band: the first / last event time of every slice of the WHOLE stream
+        (``nsof_accum_set_slice_times``; ``nsof.dist.global_slice_times``) in place of those of the staged band events."""
+        t_first = np.ascontiguousarray(t_first, np.int64)
+        t_last = np.ascontiguousarray(t_last, np.int64)
+        if t_first.shape != t_last.shape or t_first.ndim != 1:
+            raise NsofValueError("t_first / t_last: one entry per staged slice")
+        self.ctx.check(self.ctx._lib.nsof_accum_set_slice_times(self._p, t_first.ctypes.data, t_last.ctypes.data, t_first.size),
+                       "accum_set_slice_times")
+
     def run(self, first_slice, n_slices, snap_every=0):
         self.ctx.check(self.ctx._lib.nsof_accum_run(self._p, int(first_slice), int(n_slices), int(snap_every)),
                        "accum_run")

@@ -204,6 +204,22 @@ def band_slice_bounds(t_all, t_band, slice_us):
     return np.searchsorted(np.asarray(t_band), bounds, side="left").astype(np.int64)
 
 
+def global_slice_times(t_all, slice_us):
+    """-> (t_first, t_last) int64 [n_slices]: the timestamp of the first and of the last event of every slice of the
+    WHOLE stream (0 for an empty slice).  Scheme 2 tests a pixel's refractory time against the slice's first event and
+    re-arms it from the slice's last one (event_mem_sim.py:243-267): properties of the global stream, which a row band
+    cannot recover from its own events -- ``simulate_banded`` hands this table to every band."""
+    import numpy as np
+    t_all = np.asarray(t_all, np.int64)
+    bounds = np.arange(t_all[0], t_all[-1] + slice_us, slice_us)
+    idx = np.searchsorted(t_all, bounds, side="left").astype(np.int64)
+    lo, hi = idx[:-1], idx[1:]
+    some = hi > lo
+    t_first = np.where(some, t_all[np.minimum(lo, t_all.size - 1)], 0).astype(np.int64)
+    t_last = np.where(some, t_all[np.maximum(hi - 1, 0)], 0).astype(np.int64)
+    return t_first, t_last
+
+
 def collective_device(device=None):
     """Device the collectives of the current process group need their tensors on: RCCL ("nccl") only moves GPU
     memory, gloo only host memory.  ``device`` overrides (e.g. ``cuda:LOCAL_RANK`` chosen by the caller)."""
@@ -215,11 +231,14 @@ def collective_device(device=None):
 
 
 def simulate_banded(x, y, p, t, sensor_hw, slice_us, simulate_band, dst=0, device=None):
-    """Scheme-1 accumulator over row bands, one band per rank: every rank filters the (replicated, tiny) event stream
-    to its band, runs ``simulate_band(xb, yb, pb, tb, idx_b, (rows, W)) -> w [rows][W] float32`` (on a GPU:
-    ``Accumulator(rows, W, 1, ...).step(...)`` then ``.w()``), and the bands are gathered on ``dst`` (the only
-    collective, issued on ``device`` -- default: the GPU of this rank under RCCL, host memory under gloo).  Scheme 2
-    couples pixels through the slice's first/last timestamps and is run per independent stream instead."""
+    """The accumulator over row bands, one band per rank (both schemes): every rank filters the (replicated, tiny) event
+    stream to its band, runs ``simulate_band(xb, yb, pb, tb, idx_b, (rows, W), (t_first, t_last)) -> w [rows][W] float32``
+    -- or a tuple ``(w, w_b)`` for scheme 2 / split -- and the bands are gathered on ``dst`` (the only collective, issued
+    on ``device`` -- default: the GPU of this rank under RCCL, host memory under gloo).  On a GPU the callback is
+    ``Accumulator(rows, W, version, ...)``: ``set_events`` -> ``set_slice_times(t_first, t_last)`` -> ``run`` -> ``.w()``.
+    ``(t_first, t_last)`` = ``global_slice_times``: scheme 2 reads each slice's first / last event time, which belong to
+    the whole stream's slice, not to the band's events (scheme 1 ignores them); with them a band's state equals its rows
+    of the unsharded run.  Returns float32 [H][W] (or the tuple of two) on ``dst``, None elsewhere."""
     import numpy as np
     rank, world = dist.get_rank(), dist.get_world_size()
     H, W = sensor_hw  # noqa: N806
@@ -227,22 +246,28 @@ def simulate_banded(x, y, p, t, sensor_hw, slice_us, simulate_band, dst=0, devic
     xb, yb, pb, tb, _ = events_in_band(x, y, p, t, y0, y1)
     idx = band_slice_bounds(t, tb, slice_us)
     dev = collective_device(device)
-    w_band = simulate_band(xb, yb, pb, tb, idx, (y1 - y0, W))
-    if not torch.is_tensor(w_band):
-        w_band = torch.as_tensor(np.ascontiguousarray(w_band, np.float32))
+    res = simulate_band(xb, yb, pb, tb, idx, (y1 - y0, W), global_slice_times(t, slice_us))
+    arrays = list(res) if isinstance(res, (tuple, list)) else [res]
     cap = max(hi - lo for lo, hi in band_bounds(H, world))
-    buf = torch.zeros((cap, W), dtype=torch.float32, device=dev)
-    if y1 > y0:
-        buf[:y1 - y0] = w_band.to(dev).reshape(y1 - y0, W)
-    parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, parts, dst=dst)
+    outs = []
+    for w_band in arrays:
+        if not torch.is_tensor(w_band):
+            w_band = torch.as_tensor(np.ascontiguousarray(w_band, np.float32))
+        buf = torch.zeros((cap, W), dtype=torch.float32, device=dev)
+        if y1 > y0:
+            buf[:y1 - y0] = w_band.to(dev).reshape(y1 - y0, W)
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, parts, dst=dst)
+        if rank == dst:
+            outs.append(torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(band_bounds(H, world))], 0).cpu())
     if rank != dst:
         return None
-    return torch.cat([parts[r][:hi - lo] for r, (lo, hi) in enumerate(band_bounds(H, world))], 0).cpu()
+    return tuple(outs) if isinstance(res, (tuple, list)) else outs[0]
 
 
 # ---- sequence end to end: accumulator bands -> surface frames on every rank -> pairs sharded ----
-def events_to_flow_sharded(x, y, p, t, sensor_hw, slice_us, snapshot_every, band_frames, flow_of_frames, device=None):
+def events_to_flow_sharded(x, y, p, t, sensor_hw, slice_us, snapshot_every, band_frames, flow_of_frames, device=None,
+                           stats=None):
     """BASELINE config 5 over several ranks.  Pixels are independent, so the accumulator state is split into row bands
     (no halo): every rank filters the (replicated, small) event stream to its band and runs
     ``band_frames(xb, yb, pb, tb, idx_b, (rows, W), snapshot_every, n_frames) -> uint8 [n_frames][rows][W]`` -- the band
@@ -251,7 +276,10 @@ def events_to_flow_sharded(x, y, p, t, sensor_hw, slice_us, snapshot_every, band
     every rank with the full frames.  Pairs of consecutive frames are independent from then on and are sharded in
     contiguous chunks: ``flow_of_frames(frames[lo : hi + 1]) -> float32 [hi - lo][H][W][2]`` (on a GPU:
     ``nsof.farneback_sequence``).  Returns ``((lo, hi), frames, flows_local)``; without an initialised process group
-    it is the single-rank pipeline."""
+    it is the single-rank pipeline.  ``stats`` (dict) receives the wall time of the three stages on this rank, the bytes
+    the all-gather moved and what backend moved them."""
+    import time
+
     import numpy as np
     have = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if have else (0, 1)
@@ -265,9 +293,17 @@ def events_to_flow_sharded(x, y, p, t, sensor_hw, slice_us, snapshot_every, band
     xb, yb, pb, tb, _ = events_in_band(x, y, p, t, y0, y1)
     idx = band_slice_bounds(t, tb, slice_us)
     dev = collective_device(device)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    t0 = time.perf_counter()
     fb = band_frames(xb, yb, pb, tb, idx, (y1 - y0, W), snapshot_every, n_frames)
     if not torch.is_tensor(fb):
         fb = torch.as_tensor(np.ascontiguousarray(fb, np.uint8))
+    sync()
+    t1 = time.perf_counter()
     bands = band_bounds(H, world)
     if world == 1:
         frames = fb.to(dev).reshape(n_frames, H, W)
@@ -279,6 +315,15 @@ def events_to_flow_sharded(x, y, p, t, sensor_hw, slice_us, snapshot_every, band
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf)
         frames = torch.cat([parts[r][:, :hi - lo] for r, (lo, hi) in enumerate(bands)], 1).contiguous()
+    sync()
+    t2 = time.perf_counter()
     lo, hi = shard_bounds(n_frames - 1, world)[rank]
     flows = flow_of_frames(frames[lo:hi + 1]) if hi > lo else None
+    sync()
+    t3 = time.perf_counter()
+    if stats is not None:
+        cap = max(b - a for a, b in bands)
+        stats.update(rank=rank, world_size=world, backend=dist.get_backend() if have else None, band_rows=y1 - y0,
+                     band_events=int(len(tb)), frames=n_frames, pairs=(lo, hi), bands_s=t1 - t0, allgather_s=t2 - t1,
+                     flow_s=t3 - t2, allgather_bytes_received=(world - 1) * n_frames * cap * W if world > 1 else 0)
     return (lo, hi), frames, flows

@@ -174,7 +174,7 @@ def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, a
 
 
 def events_to_flow_sequence_sharded(x, y, p, t, sensor_hw, params=None, slice_us=1000, active_v=-6.0, silent_v=0.0,
-                                    snapshot_every=33, dense=True, ctx=None):
+                                    snapshot_every=33, dense=True, ctx=None, stats=None):
     """``events_to_flow_sequence`` over the ranks of the current process group (one GPU each): accumulator row bands,
     all-gather of the 8-bit surface frames, contiguous shards of the frame pairs (``nsof.dist.events_to_flow_sharded``
     with the GPU accumulator and ``farneback_sequence`` as the two stages).  Returns ``((lo, hi), frames, flows_local)``
@@ -213,7 +213,7 @@ def events_to_flow_sequence_sharded(x, y, p, t, sensor_hw, params=None, slice_us
 
     return nd.events_to_flow_sharded(x, y, p, t, (H, W), slice_us, snapshot_every, band_frames, flow_of_frames, device=dev
                                      if torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
-                                     else None)
+                                     else None, stats=stats)
 
 
 def gated_flow(gray_map, prev, nxt, cfg, flow_fn=None):

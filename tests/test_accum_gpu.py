@@ -311,7 +311,7 @@ def test_row_bands_with_real_accumulator(nsof_lib, ctx):
         W, H = 64, 47
         x, y, p, t = synth.make_events(11, W, H, 3000, 40_000, box=(12, 9))
 
-        def band(xb, yb, pb, tb, idx_b, hw):
+        def band(xb, yb, pb, tb, idx_b, hw, slice_times):
             if hw[0] == 0:
                 return np.zeros(hw, np.float32)
             acc = nsof_lib.Accumulator(hw[0], hw[1], 1, "split", -6.0, 0.0, ctx=ctx)
@@ -328,6 +328,53 @@ def test_row_bands_with_real_accumulator(nsof_lib, ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("polarity", ["split", "magnitude"])
+def test_scheme2_row_bands_stitch_to_the_unsharded_run(nsof_lib, ctx, polarity):
+    """Scheme 2 over row bands (the refractory rule reads the first / last event time of the WHOLE
+    stream's slice, /root/reference/eventsim/event_mem_sim.py:243-267): three bands, each an accumulator staged with
+    its own events + nsof_accum_set_slice_times(global table), stitched == the unsharded simulate, both arrays; and
+    WITHOUT the global table a band differs (that is what the call is for)."""
+    from nsof import dist as nd
+    from nsof import synth
+    from test_dist_cpu import _refractory_stream
+    W, H = 72, 50   # noqa: N806
+    x, y, p, t = _refractory_stream(H, W, seed=9, duration_us=60_000)   # OFF = 0, as scheme 2 / split expects (SURVEY Appendix B.8)
+    full = nsof_lib.simulate((x, y, p, t), version=2, slice_us=1000, active_v=-0.3, silent_v=0.0, polarity=polarity,
+                             sensor_size=(H, W), ctx=ctx)
+    tf, tl = nd.global_slice_times(t, 1000)
+    rows_a, rows_b, plain_differs = [], [], False
+    for (y0, y1) in nd.band_bounds(H, 3):
+        xb, yb, pb, tb, _ = nd.events_in_band(x, y, p, t, y0, y1)
+        idx = nd.band_slice_bounds(t, tb, 1000)
+        for use_table in (True, False):
+            acc = nsof_lib.Accumulator(y1 - y0, W, 2, polarity, -0.3, 0.0, ctx=ctx)
+            try:
+                acc.set_events(xb, yb, pb, tb, idx)
+                if use_table:
+                    acc.set_slice_times(tf, tl)
+                acc.run(0, len(idx) - 1)
+                wa = acc.w(0)
+                wb = acc.w(1) if polarity == "split" else None
+            finally:
+                acc.close()
+            if use_table:
+                rows_a.append(wa)
+                rows_b.append(wb)
+            else:
+                plain_differs |= not np.array_equal(wa, full["w_final"][y0:y1])
+    assert np.array_equal(np.concatenate(rows_a, 0), full["w_final"])
+    if polarity == "split":
+        assert np.array_equal(np.concatenate(rows_b, 0), full["w_final_b"])
+    assert plain_differs, "the band's own first / last event times gave the global result: the stream does not exercise the rule"
+    with pytest.raises(nsof_lib.NsofError):
+        acc = nsof_lib.Accumulator(8, 8, 2, polarity, -0.3, 0.0, ctx=ctx)
+        try:
+            acc.set_events(x[:0], y[:0], p[:0], t[:0], np.zeros(3, np.int64))
+            acc.set_slice_times(tf[:5], tl[:5])   # 2 slices staged, 5 given
+        finally:
+            acc.close()
 
 
 def test_sharded_sequence_pipeline_equals_single_gpu(nsof_lib, ctx):
