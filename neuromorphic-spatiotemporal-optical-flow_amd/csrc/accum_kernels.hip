@@ -888,7 +888,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
     // 3840x2160 0.97 vs 1.21 ms for the every-pixel pass -- both are launch bound and it needs half the launches; its cost
     // grows with the pixel count (16 B/px per 64 slices), so beyond ~12 M pixels the event-pixel update takes over.
     static const size_t auto_dense_px = [] {
-        const char* e = getenv("NSOF_ACCUM_AUTO_DENSE_PX");
+        const char* e = NSOF_AB_GETENV("NSOF_ACCUM_AUTO_DENSE_PX");
         return e ? (size_t)atoll(e) : (size_t)12 << 20;
     }();
     const bool sparse = dead_zone && a->force_dense <= 0 && (a->force_dense < 0 || !(a->scheme == 1 && a->npx <= auto_dense_px));
@@ -901,14 +901,15 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         // measured (scripts/bench_accum_v2.py, 3840x2160, 1 M events/s): the replayed graph is 7-12 % SLOWER than the
         // plain launches (split 130 k vs 140 k slices/s, magnitude 224 k vs 255 k) -- a graph node costs as much as a
         // stream launch here -- so it is opt-in
-        const char* e = getenv("NSOF_ACCUM_GRAPH");
+        const char* e = NSOF_AB_GETENV("NSOF_ACCUM_GRAPH");
         a->use_graph = (e && e[0] == '1') ? 1 : 0;
     }
     if (a->v2_per_slice < 0) {   // NSOF_ACCUM_V2=slices: round 2's one-scatter-launch-per-slice form (A/B runs)
-        const char* e = getenv("NSOF_ACCUM_V2");
+        const char* e = NSOF_AB_GETENV("NSOF_ACCUM_V2");
         a->v2_per_slice = (e && e[0] == 's') ? 1 : 0;
     }
     if (a->use_graph) a->v2_per_slice = 1;   // the graph replays the per-slice chain
+#ifdef NSOF_AB   // tuning builds only: a group's per-slice chain replayed as a HIP graph (measured 7-12 % slower than plain launches)
     if (a->scheme == 2 && a->use_graph && n_slices > 0) {
         // groups of this call (same rule as below: up to 32 slices, ending right after a snapshot slice)
         std::vector<GroupRec> groups;
@@ -987,6 +988,7 @@ static int accum_advance(nsof_accum* a, int64_t s_begin, int64_t n_slices, int64
         }
         return surf ? accum_surface(a, surf_which, *surf) : NSOF_OK;
     }
+#endif
     // the dense scheme-1 update takes groups of up to 64 slices (two mask words per pixel): a 33-slice frame interval is one
     // pass over the array instead of two
     const bool wide = a->scheme == 1 && !sparse;

@@ -173,7 +173,7 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
 
         // workspace: level images, expansions, two flow buffers (every level uses their leading part)
         const size_t szI = align_up(maxI * 4, 256), szR = align_up(maxR * 4, 256), szF = align_up(maxF * 8, 256);
-        static const bool exact_2k = [] { const char* e = getenv("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
+        static const bool exact_2k = [] { const char* e = NSOF_AB_GETENV("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
         const bool exact_x = exact && !exact_2k;   // one fused kernel (k_iterate_x); 2k: column sums through HBM
         // a list too small to fill the chip with (strip, item) jobs: the three-kernel small-batch form of the same order
         long long jobs = 0;

@@ -22,6 +22,9 @@
 namespace {
 
 
+#ifdef NSOF_AB   // tuning builds only (scripts/build_variant.sh): the walker (k_iterate) and the 2-row producer / consumer kernel
+                  // (k_iterate_pc: NSOF_ITERATE=walker|pc, NSOF_ITER_SPLIT, NSOF_PC_COLS128, NSOF_FOLD_UPSAMPLE); the product library
+                  // runs k_iterate_q (fast row sums) and k_iterate_x (library order)
 template <int MH>
 struct IterGeom {
     static constexpr int RB = 2;                               // rows per step (4 spills the register ring)
@@ -542,6 +545,8 @@ __global__ __launch_bounds__((SPLIT ? 4 : 3) * COLS) void k_iterate_pc(const flo
 }
 
 
+#endif  // NSOF_AB (walker, 2-row producer / consumer kernel)
+
 // ---------------------------------------------------------------------------------------------
 // Quad-row variant: the same role-specialised walker, FOUR rows per step.
 //
@@ -874,6 +879,8 @@ __global__ __launch_bounds__(3 * COLS) void k_iterate_q(const float* __restrict_
         q_producer_loop<MH, COLS, 1>(mring, R0, R1, F, W, H, xc, col, nsteps, yb);
 }
 
+#ifdef NSOF_AB   // tuning builds only: round 2's two-kernel form of the library's row-sum order (NSOF_EXACT_IMPL=2k, NSOF_LAT_ROWSCAN_OLD);
+                  // the product library keeps that order inside k_iterate_x / the k_lat_* kernels
 // ---------------------------------------------------------------------------------------------
 // Exact-order row sums, phase B: the reference library's running row sums + the 2x2 solve.
 //
@@ -1030,11 +1037,14 @@ int launch_iterate_q_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_item* 
     return NSOF_OK;
 }
 
+#endif  // NSOF_AB (two-kernel exact form)
+
 template <int MH>
 int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                      const float* flow_in, float* flow_out, int W, int H, int winsize)
 {
-    static const bool narrow = getenv("NSOF_Q_COLS128") != nullptr;   // A/B: two 128-column strips per CU
+#ifdef NSOF_AB
+    static const bool narrow = NSOF_AB_GETENV("NSOF_Q_COLS128") != nullptr;   // A/B: two 128-column strips per CU
     if (narrow) {
         using G = QGeom<MH, 128>;
         if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false, 128>, G::SMEM)) return rc;
@@ -1043,6 +1053,7 @@ int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R
                            flow_in, flow_out, W, H, winsize, nullptr, 0);
         return NSOF_OK;
     }
+#endif
     using G = QGeom<MH>;
     if (int rc = lds_opt_in(ctx, k_iterate_q<MH, false>, G::SMEM)) return rc;
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
@@ -1082,6 +1093,7 @@ int launch_iterate_q_het(nsof_ctx* ctx, int n_items, const nsof_het_item* items,
     return NSOF_OK;
 }
 
+#ifdef NSOF_AB
 template <int MH, int COLS, bool UPS>
 int launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                         const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
@@ -1089,7 +1101,7 @@ int launch_iterate_pc_c(nsof_ctx* ctx, int n_pairs, const float* R0, const float
     using G = PCGeom<MH, COLS>;
     dim3 grid((W + G::SW - 1) / G::SW, 1, n_pairs);
     if constexpr (!UPS && COLS == 256) {
-        static const bool split = getenv("NSOF_ITER_SPLIT") != nullptr;   // 16-wave layout (A/B)
+        static const bool split = NSOF_AB_GETENV("NSOF_ITER_SPLIT") != nullptr;   // 16-wave layout (A/B)
         if (split) {
             if (int rc = lds_opt_in(ctx, k_iterate_pc<MH, COLS, false, false, true>, G::SMEM)) return rc;
             hipLaunchKernelGGL((k_iterate_pc<MH, COLS, false, false, true>), grid, dim3(4 * COLS), G::SMEM, ctx->stream,
@@ -1119,7 +1131,7 @@ template <int MH, bool UPS>
 int launch_iterate_pc(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                        const float* flow_in, float* flow_out, int W, int H, int winsize, const UpsArgs& ups)
 {
-    static const bool narrow = getenv("NSOF_PC_COLS128") != nullptr;   // tuning experiment: 2 blocks of 128 columns per CU
+    static const bool narrow = NSOF_AB_GETENV("NSOF_PC_COLS128") != nullptr;   // tuning experiment: 2 blocks of 128 columns per CU
     if (!UPS && narrow)
         return launch_iterate_pc_c<MH, 128, false>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
     return launch_iterate_pc_c<MH, 256, UPS>(ctx, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, ups);
@@ -1150,25 +1162,35 @@ void launch_iterate_m(nsof_ctx* ctx, int n_pairs, const float* R0, const float* 
                        winsize);
 }
 
+#endif  // NSOF_AB
+
 }  // namespace
 
 bool nsof_iterate_supported(int winsize, int W, int H)
 {
     const int m = winsize / 2;
-    return m >= 1 && m <= 8 && W >= 2 && H >= 2;   // the clamped gather needs a 2x2 neighbourhood to exist
+#ifdef NSOF_AB
+    return m >= 1 && m <= 8 && W >= 2 && H >= 2;   // (the walker of the tuning builds also takes winsize 16 / 17)
+#else
+    return m >= 1 && m <= 7 && W >= 2 && H >= 2;   // the clamped gather needs a 2x2 neighbourhood to exist
+#endif
 }
 
+#ifdef NSOF_AB
 static int g_iterate_variant = -1;   // NSOF_ITERATE=walker|pc|quad (tuning / A-B runs); default quad
 static int iterate_variant()
 {
     if (g_iterate_variant < 0) {
-        const char* e = getenv("NSOF_ITERATE");
+        const char* e = NSOF_AB_GETENV("NSOF_ITERATE");
         g_iterate_variant = (e && e[0] == 'w') ? 0 : (e && e[0] == 'p') ? 1 : 2;
     }
     return g_iterate_variant;
 }
 static bool use_pc(int m) { return iterate_variant() >= 1 && m <= 7; }
 static bool use_quad(int m) { return iterate_variant() == 2 && m <= 7; }
+#else
+static bool use_quad(int m) { return m <= 7; }
+#endif
 
 template <typename... A>
 static int launch_iterate_q_m(int m, A... a)
@@ -1208,6 +1230,7 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
         NSOF_HIP(ctx, hipGetLastError());
         return NSOF_OK;
     }
+#ifdef NSOF_AB
     if (use_pc(winsize / 2)) {
         if (int rc = launch_iterate_pc_m<false>(ctx, winsize / 2, n_pairs, R0, R1, pair_stride, flow_in, flow_out, W, H,
                                                 winsize, UpsArgs{}))
@@ -1228,12 +1251,21 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
     }
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
+#else
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "fused iteration supports winsize 2..15");
+#endif
 }
 
-// First iteration of a level, reading the previous (coarser) level's flow and resampling it on the fly.
+// First iteration of a level, reading the previous (coarser) level's flow and resampling it on the fly (tuning builds
+// only: NSOF_FOLD_UPSAMPLE measured slower than the standalone resample kernel).
 bool nsof_iterate_upsample_supported(int winsize, int W, int H)
 {
+#ifdef NSOF_AB
     return nsof_iterate_supported(winsize, W, H) && use_pc(winsize / 2);
+#else
+    (void)winsize; (void)W; (void)H;
+    return false;
+#endif
 }
 
 int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
@@ -1242,6 +1274,7 @@ int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, co
 {
     if (!nsof_iterate_upsample_supported(winsize, W, H))
         return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "fused upsample+iteration not available for winsize %d", winsize);
+#ifdef NSOF_AB
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     UpsArgs ups;
     ups.sw = sw;
@@ -1253,6 +1286,7 @@ int nsof_launch_iterate_upsample(nsof_ctx* ctx, int n_pairs, const float* R0, co
                                            winsize, ups))
         return rc;
     NSOF_HIP(ctx, hipGetLastError());
+#endif
     return NSOF_OK;
 }
 
@@ -1269,6 +1303,9 @@ int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
         NSOF_HIP(ctx, hipGetLastError());
         return NSOF_OK;
     }
+#ifndef NSOF_AB
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "work-list iteration supports winsize 2..15");
+#else
     switch (m) {
         case 1: rc = launch_iterate_pc_het<1>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
         case 2: rc = launch_iterate_pc_het<2>(ctx, n_items, d_items, max_w, R, flow_in, flow_out, final, winsize); break;
@@ -1281,8 +1318,11 @@ int nsof_launch_iterate_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_i
     if (rc) return rc;
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
+#endif
 }
 
+// Round 2's two-kernel form of the library's row-sum order (tuning builds only; see the NSOF_AB section above).
+#ifdef NSOF_AB
 // Exact-order twin of nsof_launch_iterate: phase A (fused matrix update + column sums -> vsum) and phase B (row scan
 // + solve).  vsum: n_pairs * 5 * W * H doubles of scratch.  winsize 2..15.
 // Phase B on its own (the small-batch form, farneback_iterate_lat.hip, forms the column sums with its own kernels).
@@ -1350,3 +1390,24 @@ int nsof_launch_iterate_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_ite
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
 }
+
+#else
+bool nsof_iterate_exact_supported(int, int, int) { return false; }
+int nsof_launch_rowscan_solve(nsof_ctx* ctx, int, const double*, int, int, int, float*)
+{
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "two-kernel exact form: tuning builds only");
+}
+int nsof_launch_rowscan_solve_het(nsof_ctx* ctx, int, const nsof_het_item*, int, const double*, float*, bool, int)
+{
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "two-kernel exact form: tuning builds only");
+}
+int nsof_launch_iterate_exact(nsof_ctx* ctx, int, const float*, const float*, size_t, const float*, float*, int, int, int, double*)
+{
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "two-kernel exact form: tuning builds only");
+}
+int nsof_launch_iterate_het_exact(nsof_ctx* ctx, int, const nsof_het_item*, int, int, const float*, const float*, float*, bool, int,
+                                  double*)
+{
+    return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "two-kernel exact form: tuning builds only");
+}
+#endif

@@ -411,11 +411,13 @@ int launch_lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const doub
 int lat_rowscan(nsof_ctx* ctx, int n, int W, int H, int max_h, const double* V, int winsize, float* flow_out,
                 const nsof_het_item* items, bool final)
 {
-    static const bool old = getenv("NSOF_LAT_ROWSCAN_OLD") != nullptr;   // A/B: the two-kernel form's row scan
+#ifdef NSOF_AB
+    static const bool old = NSOF_AB_GETENV("NSOF_LAT_ROWSCAN_OLD") != nullptr;   // A/B: the two-kernel form's row scan
     if (old)
         return items ? nsof_launch_rowscan_solve_het(ctx, n, items, max_h, V, flow_out, final, winsize)
                      : nsof_launch_rowscan_solve(ctx, n, V, W, H, winsize, flow_out);
-    static const int rows_env = [] { const char* e = getenv("NSOF_LR_ROWS"); return e ? atoi(e) : 0; }();   // A/B: 4 or 8
+#endif
+    static const int rows_env = [] { const char* e = NSOF_AB_GETENV("NSOF_LR_ROWS"); return e ? atoi(e) : 0; }();   // A/B: 4 or 8
     const bool rows4 = rows_env ? rows_env == 4 : (long long)((max_h + 3) / 4) * n <= 256;
     switch (winsize / 2) {
 #define NSOF_LR(MM)                                                                                                  \

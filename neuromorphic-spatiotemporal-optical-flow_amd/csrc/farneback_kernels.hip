@@ -1697,12 +1697,16 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
-    static const bool mono = [] { const char* e = getenv("NSOF_POLYEXP"); return e && e[0] == 'm'; }();   // A/B: single-role kernel
+#ifdef NSOF_AB
+    static const bool mono = [] { const char* e = NSOF_AB_GETENV("NSOF_POLYEXP"); return e && e[0] == 'm'; }();   // A/B: single-role kernel
+#endif
     if (ctx->opt_polyexp_f32)
         hipLaunchKernelGGL((k_polyexp<N, false, true>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps,
                            nullptr);
+#ifdef NSOF_AB   // NSOF_POLYEXP=mono: the single-role kernel with the exact arithmetic (superseded by k_polyexp_rs)
     else if (mono)
         hipLaunchKernelGGL((k_polyexp<N, false>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
+#endif
     else
         hipLaunchKernelGGL((k_polyexp_rs<N, false>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr);
 }
@@ -1754,14 +1758,14 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
                                (taps.ksize == 3 || taps.ksize == 5);   // larger kernels: registers run out
         // exact decimation by 2 / 4 / 8 with the kernel sizes the pyr_scale 0.5 pyramid produces
         const int S = W / wk;
-        static const bool force8 = getenv("NSOF_DECIM_CW8") != nullptr;   // A/B: 8-column lanes everywhere
+        static const bool force8 = NSOF_AB_GETENV("NSOF_DECIM_CW8") != nullptr;   // A/B: 8-column lanes everywhere
         const int CWL = ((W & 15) == 0 && !force8) ? 16 : 8;   // source columns per lane
         const bool decim_ok = S >= 2 && W == S * wk && H == S * hk && (W % CWL) == 0 && W >= 64 &&
                               (row_stride % CWL) == 0 && (img_stride % CWL) == 0 &&
                               (reinterpret_cast<uintptr_t>(src) % CWL) == 0 &&
                               ((S == 2 && taps.ksize == 3) || (S == 4 && taps.ksize == 9) ||
                                (S == 8 && taps.ksize == 19)) &&
-                              H > taps.ksize && getenv("NSOF_PREP_NODECIM") == nullptr;
+                              H > taps.ksize && NSOF_AB_GETENV("NSOF_PREP_NODECIM") == nullptr;
         if (decim_ok) {
             // segments of output rows: multiples of the unroll count, ~16 source rows of warm-up amortised
             const int U = S == 2 ? 2 : 3;
@@ -1822,7 +1826,7 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
             if (taps.ksize == 3) NSOF_PREP_DIRECT(3);
             else NSOF_PREP_DIRECT(5);
 #undef NSOF_PREP_DIRECT
-        } else if (taps.ksize == 19 && scale_x >= 1.0 && scale_y >= 1.0 && getenv("NSOF_PREP_TILED") == nullptr) {
+        } else if (taps.ksize == 19 && scale_x >= 1.0 && scale_y >= 1.0 && NSOF_AB_GETENV("NSOF_PREP_TILED") == nullptr) {
             // measured at 1080p x 64 frames: 19 taps 459 -> 244 us; 9 taps is still faster tiled (231 vs 254 us)
             int rc = nsof_ws_reserve(ctx, &ctx->tmp, &ctx->tmp_bytes, (size_t)n_img * H * 2 * wk * sizeof(float));
             if (rc) return rc;
@@ -1916,7 +1920,7 @@ int NSOF_PYR_NAME(nsof_launch_flow_upsample)(nsof_ctx* ctx, int n_pairs, const f
 {
     nsof_prof_scope ps(ctx, NSOF_K_UPSAMPLE);
     const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
-    if (dw >= sw && dh >= sh && sw >= 1 && sh >= 1 && dw >= 256 && getenv("NSOF_UPSAMPLE_2X2") == nullptr) {
+    if (dw >= sw && dh >= sh && sw >= 1 && sh >= 1 && dw >= 256 && NSOF_AB_GETENV("NSOF_UPSAMPLE_2X2") == nullptr) {
         // upsampling: source steps of 0 or 1 between neighbours; rows wide enough for a lane per 2 columns
         dim3 g(((dw + 1) / 2 + 255) / 256, (dh + UPW_SEG - 1) / UPW_SEG, n_pairs);
         hipLaunchKernelGGL(k_flow_upsample_walk, g, dim3(256), 0, ctx->stream, src, sw, sh, dst, dw, dh, scale_x,

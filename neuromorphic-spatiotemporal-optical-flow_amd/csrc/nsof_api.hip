@@ -606,8 +606,8 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     const bool exact = ctx->opt_exact_rowsums != 0;
     // exact row-sum order: ONE fused kernel (k_iterate_x) where the window fits; NSOF_EXACT_IMPL=2k selects the older
     // two-kernel form (column sums through HBM) for A/B runs
-    static const bool exact_2k = [] { const char* e = getenv("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
-    static const char* fused_env0 = getenv("NSOF_FUSED");
+    static const bool exact_2k = [] { const char* e = NSOF_AB_GETENV("NSOF_EXACT_IMPL"); return e && e[0] == '2'; }();
+    static const char* fused_env0 = NSOF_AB_GETENV("NSOF_FUSED");
     const bool exact_x = exact && !exact_2k && !(fused_env0 && fused_env0[0] == '0') && iterations > 0 &&
                          nsof_iterate_x_supported(winsize, width, height);
     // a batch too small to fill the chip with (strip, image) jobs takes the three-kernel small-batch form of the same
@@ -615,7 +615,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     const bool exact_lat = exact_x && (long long)n_pairs * ((width + 191) / 192) <= ctx->opt_small_batch_jobs &&
                            (unsigned long long)width * height * 40ull < (1ull << 32);   // its kernels address a pair with 32-bit byte offsets
     static const int exact_chunk = [] {
-        const char* e = getenv("NSOF_EXACT_CHUNK");
+        const char* e = NSOF_AB_GETENV("NSOF_EXACT_CHUNK");
         const int v = e ? atoi(e) : 64;
         return v < 1 ? 1 : v;
     }();
@@ -674,7 +674,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     const size_t n_img = sequence ? B + 1 : 2 * B;   // frames of a sequence, or B prev + B next frames
     // Fused or unfused is decided once for the whole pyramid (inputs below 2x2 take the unfused pair).
     // NSOF_FUSED=0 forces the unfused pair (A/B runs; measured slower even for a lone 1080p pair: 6.1 vs 4.0 ms).
-    static const char* fused_env = getenv("NSOF_FUSED");
+    static const char* fused_env = NSOF_AB_GETENV("NSOF_FUSED");
     // exact row-sum order: the fused two-kernel form (phase A + row scan) where the window fits, else the unfused kernels
     const bool exact_fused = exact && (exact_x || (nsof_iterate_exact_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0')));
     const bool fused = nsof_iterate_supported(winsize, width, height) && !(fused_env && fused_env[0] == '0') &&
@@ -697,7 +697,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // it; then only iterations move the flow between the buffers.
     // Measured on MI355X (1080p x 128 pairs): folding costs more in the producers (4 gathers + the resample per
     // row, 168 VGPRs) than the standalone resample kernel saves (24.6 -> 25.5 ms per step), so it is opt-in.
-    static const bool fold_env = getenv("NSOF_FOLD_UPSAMPLE") != nullptr;
+    static const bool fold_env = NSOF_AB_GETENV("NSOF_FOLD_UPSAMPLE") != nullptr;
     const bool fold_ups = fold_env && fused && !exact && iterations > 0 &&
                           nsof_iterate_upsample_supported(winsize, width, height);
     const int flips = fused ? (fold_ups ? (L + 1) * iterations : L * (1 + iterations) + iterations) : L;
@@ -711,7 +711,10 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // Measured (256 pairs 1080p): every kernel slows down by what the others gain -- iterate 23.7 -> 26.3 ms, polyexp
     // 8.9 -> 10.4, prep 2.9 -> 3.9, resample 1.5 -> 2.3 per step, 6877 vs 6804 pairs/s -- there is no idle capacity to
     // harvest next to these kernels, so the single-stream order stays the default.
-    static const bool overlap_env = [] { const char* e = getenv("NSOF_OVERLAP"); return e && e[0] == '1'; }();
+#ifdef NSOF_AB
+    static const bool overlap_env = [] { const char* e = NSOF_AB_GETENV("NSOF_OVERLAP"); return e && e[0] == '1'; }();
+#endif
+#ifdef NSOF_AB   // tuning builds only: NSOF_OVERLAP=1 (level overlap on a side stream; measured no faster)
     if (fused && !exact && !fold_ups && overlap_env && L >= 1 && iterations > 0) {
         if (!ctx->side) NSOF_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         while (ctx->ov_events.size() < (size_t)4 * (L + 1)) {
@@ -788,6 +791,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
             NSOF_HIP(ctx, hipMemcpyAsync(d_flow, fb[cur], B * n0 * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return NSOF_OK;
     }
+#endif
 
     bool have_prev = false;
     int pw = 0, ph = 0;

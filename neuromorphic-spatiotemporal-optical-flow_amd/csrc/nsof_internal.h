@@ -69,6 +69,17 @@ struct nsof_ctx {
     bool x_dirty = false;
 };
 
+// Tuning / A-B switches.  Only builds made by scripts/build_variant.sh (-DNSOF_AB) read them; in the product library each
+// of them is the constant "unset" and the larger kernels they select are not compiled (#ifdef NSOF_AB in the sources).
+// The environment variables the PRODUCT reads are the context defaults documented in include/nsof.h (NSOF_POLYEXP_F32,
+// NSOF_EXACT_ROWSUMS, NSOF_PYR_FMA, NSOF_LAT_JOBS, NSOF_ROW_BANDS), the pipelined entry's NSOF_PIPE_CHUNK_MB /
+// NSOF_PIPE_FAIL_AFTER_CHUNK / NSOF_PIPE_TRACE and the chunking cap NSOF_MAX_PAIRS (test hooks).
+#ifdef NSOF_AB
+#define NSOF_AB_GETENV(name) getenv(name)
+#else
+#define NSOF_AB_GETENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 int nsof_set_error(nsof_ctx* ctx, int code, const char* fmt, ...);
 int nsof_ws_reserve(nsof_ctx* ctx, void** buf, size_t* cur, size_t need);
 // Page-locked host memory on the GPU's NUMA node (best effort); NUMA node of a device from sysfs, -1 if unknown.

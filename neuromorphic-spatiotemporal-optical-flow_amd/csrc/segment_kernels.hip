@@ -286,7 +286,7 @@ int run_chain(nsof_ctx* ctx, uint32_t* bits, uint32_t* scratch, int w, int h, co
             return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "structuring element too tall for the LDS tile");
         const bool last = done + chunk >= n_pass;
         constexpr MorphElem e10 = ellipse10();
-        const bool fixed10 = memcmp(&el, &e10, sizeof(MorphElem)) == 0 && getenv("NSOF_MORPH_GENERIC") == nullptr;
+        const bool fixed10 = memcmp(&el, &e10, sizeof(MorphElem)) == 0 && NSOF_AB_GETENV("NSOF_MORPH_GENERIC") == nullptr;
         auto kern = fixed10 ? k_morph_bits<true> : k_morph_bits<false>;
         if (smem > 64 * 1024)
             NSOF_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -9,7 +9,7 @@ make -s
 mkdir -p build/var_$name
 base=$(basename "$src" .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value \
-    -Wno-unused-result -I../include -Icsrc $flags -c csrc/$base.hip -o build/var_$name/$base.o
+    -Wno-unused-result -DNSOF_AB -I../include -Icsrc $flags -c csrc/$base.hip -o build/var_$name/$base.o
 objs=""
 for o in build/*.o; do
   if [ "$(basename $o)" = "$base.o" ]; then objs="$objs build/var_$name/$base.o"; else objs="$objs $o"; fi

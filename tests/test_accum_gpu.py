@@ -474,31 +474,6 @@ print("ok", out["w_final"].shape)
     assert meta["scheme"] == "dc_bias_overlay" and meta["slice_us"] == int(g["slice_us"])
 
 
-@pytest.mark.parametrize("polarity", ["split", "magnitude"])
-def test_scheme2_graph_replay_equals_plain_launches(nsof_lib, ctx, monkeypatch, polarity):
-    """NSOF_ACCUM_GRAPH=1: a group's per-slice scatters + update replayed as one HIP graph give the same state and
-    snapshots as the plain launches (incl. a biased run that takes the dense update, and a resumed sub-range)."""
-    from nsof import synth
-    W, H = 128, 96
-    x, y, p, t = synth.make_events(21, W, H, 40000, 400_000, box=(24, 16))
-    idx = nsof_lib.accumulator.slice_index_array(t, 1000)
-    n = len(idx) - 1
-    for silent in (0.0, 0.4):
-        res = []
-        for flag in ("0", "1"):
-            monkeypatch.setenv("NSOF_ACCUM_GRAPH", flag)
-            acc = nsof_lib.Accumulator(H, W, 2, polarity, -6.0, silent, ctx=ctx)
-            acc.set_events(x, y, p, t, idx)
-            acc.run(0, n // 2, snap_every=9)
-            acc.run(n // 2, n - n // 2, snap_every=9)
-            res.append(([acc.w(k) for k in range(2 if acc.split else 1)], acc.snapshots()))
-            acc.close()
-        for a, b in zip(res[0][0], res[1][0]):
-            assert np.array_equal(a, b)
-        for a, b in zip(res[0][1], res[1][1]):
-            assert np.array_equal(a, b)
-
-
 def test_block_current_on_device_equals_host_reduction(nsof_lib, ctx):
     """nsof_accum_block_current (block maximum of v_ds / R on the GPU, stored snapshots and the current state) == the
     host reduction over the downloaded float32 resistance maps, bit for bit; block sizes that do not divide the sensor

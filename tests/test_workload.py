@@ -340,8 +340,8 @@ def test_exact_rowsum_order_equals_oracle_on_real_frames(nsof_lib, ctx, oracle, 
     """Default mode (NSOF_OPT_EXACT_ROWSUMS = 1): with the box-filter row sums formed in the library's order (one running
     sum per image row) the HIP path equals the CPU oracle BIT FOR BIT on the reference's real frames -- the 801x801
     autodriving pairs with the 3x3 window of parameter set B, where per-pixel window sums differ by up to 7.8e-4 at 80
-    pixels -- through the per-call entry, the uniform batch / sequence and the work list; the older two-kernel form of the
-    same order (NSOF_EXACT_IMPL=2k is read once per process, so it is not exercised here) is covered by the soak script."""
+    pixels -- through the per-call entry, the uniform batch / sequence and the work list (the older two-kernel form of the
+    same order now exists in tuning builds only: `make ab`)."""
     pil = pytest.importorskip("PIL.Image")
     import torch
     from nsof import _lib, gating
