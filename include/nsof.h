@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define NSOF_ABI_VERSION 2   /* 2: NSOF_OPT_EXACT_ROWSUMS defaults to 1; option ranges validated */
+#define NSOF_ABI_VERSION 3   /* 2: NSOF_OPT_EXACT_ROWSUMS defaults to 1; option ranges validated.  3: gate_frame argument of
+                              * nsof_farneback_u8_roi_sequence_dev, nsof_accum_set_slice_times, NSOF_OPT_DEBUG_FAULT; a lost
+                              * hand-over fails the synchronising call */
 
 typedef enum nsof_status {
     NSOF_OK = 0,
@@ -170,7 +172,9 @@ int nsof_farneback_u8_batch_desc_dev(nsof_ctx* ctx, int n_pairs, const nsof_pair
  * /root/reference/optical_flow_seg.py:129-164, 186-204): d_frames = n_frames 8-bit frames in HBM, d_counts / d_rects = the
  * ROI table nsof_roi_from_surface_dev wrote (rects [n_frames][max_rects][4] = x0, y0, x1, y1), d_flows =
  * [n_frames - 1][height][width][2] float canvases, zero-filled here.  Pair k = (frame k, frame k + 1) is gated by the
- * rectangles of frame k + 1; every crop of every pair is one item of ONE work list, written into the canvas in place;
+ * rectangles of frame k + gate_frame: 1 = the map of the pair's second frame (what opticalFlow3D is written to use,
+ * memimg2), 0 = the map of its first frame (what the shipped scripts pass: memimg2 := memimg1, optical_flow_seg.py:435 --
+ * the bug-compatible default of nsof.gating); every crop of every pair is one item of ONE work list, written into the canvas in place;
  * a crop that overlaps an earlier crop of its pair is pasted after it, in label order, as the reference's loop
  * overwrites.  Each crop's flow equals nsof_farneback_u8 of that crop bit for bit.  Only the rectangle table crosses
  * PCIe (the work list's shapes are needed on the host; the call synchronises the stream once for it).  n_calls /
@@ -179,7 +183,7 @@ int nsof_farneback_u8_roi_sequence_dev(nsof_ctx* ctx, int n_frames, const uint8_
                                        ptrdiff_t frame_stride, int width, int height, const int32_t* d_counts,
                                        const int32_t* d_rects, int max_rects, float* d_flows, double pyr_scale, int levels,
                                        int winsize, int iterations, int poly_n, double poly_sigma, int flags,
-                                       long long* n_calls, long long* n_pixels);
+                                       int gate_frame, long long* n_calls, long long* n_pixels);
 /* Page-locked host memory for frames / flow fields handed to nsof_farneback_u8_batch (NULL on failure). */
 void* nsof_host_alloc(size_t bytes);
 void nsof_host_free(void* p);

@@ -395,8 +395,10 @@ extern "C" int nsof_farneback_u8_batch_desc_dev(nsof_ctx* ctx, int n_pairs, cons
 
 // Gated sequence on the device: frames [n_frames][height] rows of row_stride bytes, the ROI table of the gating kernel
 // (nsof_roi_from_surface_dev: counts [n_frames], rects [n_frames][max_rects][4] = x0, y0, x1, y1), flow canvases
-// [n_frames - 1][height][width][2].  Pair k = (frame k, frame k + 1) is gated by the rectangles of frame k + 1
-// (optical_flow_seg.py:129-164, 186-204); every crop of every pair becomes one work item, results land in the zeroed
+// [n_frames - 1][height][width][2].  Pair k = (frame k, frame k + 1) is gated by the rectangles of frame k + gate_frame:
+// gate_frame 1 = the map of the pair's SECOND frame, what opticalFlow3D is written to use (memimg2, optical_flow_seg.py:211-252);
+// gate_frame 0 = the map of its FIRST frame, what the shipped scripts actually pass (memimg2 := memimg1, optical_flow_seg.py:435;
+// the bug-compatible default of nsof.gating).  Every crop of every pair becomes one work item, results land in the zeroed
 // canvases in place; a crop that overlaps an earlier crop of its pair (FLAG 1, extended component boxes) is computed into
 // a private buffer and pasted afterwards, in label order, as the reference's loop overwrites.  The only traffic over
 // PCIe is the rectangle table (16 bytes per ROI): the work list's shapes are needed on the host.
@@ -404,11 +406,11 @@ extern "C" int nsof_farneback_u8_roi_sequence_dev(nsof_ctx* ctx, int n_frames, c
                                                   ptrdiff_t frame_stride, int width, int height, const int32_t* d_counts,
                                                   const int32_t* d_rects, int max_rects, float* d_flows, double pyr_scale,
                                                   int levels, int winsize, int iterations, int poly_n, double poly_sigma,
-                                                  int flags, long long* n_calls, long long* n_pixels)
+                                                  int flags, int gate_frame, long long* n_calls, long long* n_pixels)
 {
     if (!ctx) return NSOF_EINVAL;
     if (!d_frames || !d_counts || !d_rects || !d_flows || n_frames < 2 || max_rects < 1 || width < 1 || height < 1 ||
-        row_stride < width)
+        row_stride < width || (gate_frame != 0 && gate_frame != 1))
         return nsof_set_error(ctx, NSOF_EINVAL, "roi_sequence: bad argument");
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     const size_t canvas = (size_t)width * height * 2;   // floats per pair
@@ -424,10 +426,10 @@ extern "C" int nsof_farneback_u8_roi_sequence_dev(nsof_ctx* ctx, int n_frames, c
     size_t tmp_floats = 0;
     long long pixels = 0;
     for (int k = 0; k + 1 < n_frames; k++) {
-        const int cnt = counts[k + 1];
+        const int cnt = counts[k + gate_frame];
         if (cnt < 0 || cnt > max_rects)
-            return nsof_set_error(ctx, NSOF_EINVAL, "roi_sequence: frame %d has %d rectangles, the table holds %d", k + 1, cnt, max_rects);
-        const int32_t* r = rects.data() + (size_t)(k + 1) * max_rects * 4;
+            return nsof_set_error(ctx, NSOF_EINVAL, "roi_sequence: frame %d has %d rectangles, the table holds %d", k + gate_frame, cnt, max_rects);
+        const int32_t* r = rects.data() + (size_t)(k + gate_frame) * max_rects * 4;
         for (int i = 0; i < cnt; i++) {
             const int x0 = r[4 * i], y0 = r[4 * i + 1], x1 = r[4 * i + 2], y1 = r[4 * i + 3];
             if (x1 <= x0 || y1 <= y0) continue;

@@ -49,7 +49,7 @@ SIGNATURES = {
     "nsof_farneback_u8_sequence_dev": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_batch": (_i, [_vp, _i, C.POINTER(PairDesc), _d, _i, _i, _i, _i, _d, _i]),
     "nsof_farneback_u8_batch_desc_dev": (_i, [_vp, _i, C.POINTER(PairDesc), _d, _i, _i, _i, _i, _d, _i]),
-    "nsof_farneback_u8_roi_sequence_dev": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _vp, _i, _vp, _d, _i, _i, _i, _i, _d, _i,
+    "nsof_farneback_u8_roi_sequence_dev": (_i, [_vp, _i, _vp, _pd, _pd, _i, _i, _vp, _vp, _i, _vp, _d, _i, _i, _i, _i, _d, _i, _i,
                                                 C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "nsof_host_alloc": (_vp, [_sz]),
     "nsof_host_free": (None, [_vp]),

@@ -248,12 +248,15 @@ def farneback_pairs_dev(pairs, flows, params, *, ctx=None):
     ctx.check(rc, "farneback_pairs_dev")
 
 
-def farneback_roi_sequence_dev(frames, counts, rects, flows, params, *, ctx=None):
+def farneback_roi_sequence_dev(frames, counts, rects, flows, params, *, gate_frame=0, ctx=None):
     """The gated path of a frame sequence on the device (``nsof_farneback_u8_roi_sequence_dev``; opticalFlow3D's crop ->
     flow -> paste loop, optical_flow_seg.py:129-164, 186-204): ``frames`` uint8 CUDA tensor [n][H][W] (row stride free),
     ``counts`` / ``rects`` the device ROI table of ``gating.roi_from_surface_dev``, ``flows`` float32 CUDA tensor
-    [n-1][H][W][2] (contiguous; zero-filled by the call).  Pair k is gated by the rectangles of frame k+1; all crops of
-    all pairs form one work list; overlapping crops of a pair are pasted in label order.  -> (n_crops, crop_pixels)."""
+    [n-1][H][W][2] (contiguous; zero-filled by the call).  Pair k is gated by the rectangles of frame ``k + gate_frame``:
+    0 (default) = the map of the pair's first frame, as the shipped scripts gate (``memimg2 := memimg1``,
+    optical_flow_seg.py:435; ``GatingConfig.bug_compatible``), 1 = the map of its second frame (what ``opticalFlow3D``
+    is written to use).  All crops of all pairs form one work list; overlapping crops of a pair are pasted in label order.
+    -> (n_crops, crop_pixels)."""
     ctx = ctx or default_context()
     kw = params.as_kwargs() if hasattr(params, "as_kwargs") else dict(params)
     n, h, w = (int(v) for v in frames.shape)
@@ -265,7 +268,8 @@ def farneback_roi_sequence_dev(frames, counts, rects, flows, params, *, ctx=None
     rc = ctx._lib.nsof_farneback_u8_roi_sequence_dev(
         ctx.ptr, n, dev_ptr(frames), int(frames.stride(1)), int(frames.stride(0)), w, h, dev_ptr(counts), dev_ptr(rects),
         int(rects.shape[1]), dev_ptr(flows), float(kw["pyr_scale"]), int(kw["levels"]), int(kw["winsize"]),
-        int(kw["iterations"]), int(kw["poly_n"]), float(kw["poly_sigma"]), int(kw["flags"]), C.byref(calls), C.byref(pixels))
+        int(kw["iterations"]), int(kw["poly_n"]), float(kw["poly_sigma"]), int(kw["flags"]), int(gate_frame), C.byref(calls),
+        C.byref(pixels))
     ctx.check(rc, "farneback_roi_sequence_dev")
     return calls.value, pixels.value
 

@@ -36,6 +36,15 @@ def events_to_rois(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slic
     H, W = sensor_hw  # noqa: N806
     idx = slice_index_array(t, slice_us)
     rows, cols = H // cfg.MEMSIZE, W // cfg.MEMSIZE
+    if rows > 64 or cols > 64:
+        # the gating kernel holds a map in one wavefront (64 x 64 cells at most: the reference's maps are 13 x 24 and
+        # smaller); larger maps -- e.g. a 1280 x 720 sensor with MEMSIZE 8 -- take the host mirror of the same arithmetic
+        out = events_to_rois_host(x, y, p, t, sensor_hw, cfg, version, polarity, slice_us, active_v, silent_v,
+                                  snapshot_every, ctx=ctx)
+        if cfg.FLAG == 2:   # the union box, as the device kernel returns it
+            out = [(g, [(min(r[0] for r in rs), min(r[1] for r in rs), max(r[2] for r in rs), max(r[3] for r in rs))] if rs else [])
+                   for g, rs in out]
+        return out
     acc = Accumulator(H, W, version, polarity, active_v, silent_v, ctx=ctx)
     try:
         acc.step(x, y, p, t, idx, snap_every=snapshot_every)
@@ -47,6 +56,11 @@ def events_to_rois(x, y, p, t, sensor_hw, cfg, version=1, polarity="split", slic
             acc.block_current_dev(cfg.MEMSIZE, cur[k], snapshot=k)
         counts, rects, gray = gating.roi_from_surface_dev(cur, n, (rows, cols), (H, W), cfg, max_rects=max_rects, ctx=ctx,
                                                           want_gray=True)
+        ctx.synchronize()
+        most = int(counts.max().item())
+        if most > max_rects:   # a map with more components than the table holds: one more (tiny) launch with room for all
+            counts, rects, gray = gating.roi_from_surface_dev(cur, n, (rows, cols), (H, W), cfg, max_rects=most, ctx=ctx,
+                                                              want_gray=True)
         lists = gating.rects_to_host(counts, rects, ctx=ctx)
         g = gray.cpu().numpy()
     finally:
@@ -83,12 +97,14 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
     ``snapshot_every`` slices an 8-bit surface frame AND the gating map of the same state -> ROI rectangles on the device
     (``gating.roi_from_surface_dev``) -> Farneback flow of every ROI crop between consecutive surface frames, all crops of
     all pairs as ONE work list (``farneback_roi_sequence_dev``), written into frame-sized zero canvases exactly as
-    ``opticalFlow3D`` pastes them (optical_flow_seg.py:129-164, 186-204: pair (k, k+1) is gated by the map of frame k+1;
-    with FLAG 1 overlapping component boxes are pasted in label order, later ones winning).
+    ``opticalFlow3D`` pastes them (optical_flow_seg.py:129-164, 186-204; with FLAG 1 overlapping component boxes are pasted
+    in label order, later ones winning).  Which map gates pair (k, k+1) follows ``cfg.bug_compatible`` like the host
+    harness (``gating.gating_maps``): True (the default) = the map of frame k, as the shipped scripts do
+    (``memimg2 := memimg1``, optical_flow_seg.py:435), False = the map of frame k+1, as ``opticalFlow3D`` is written.
     Events are uploaded once; frames, maps, rectangles and flow stay in HBM -- the only thing that crosses PCIe before the
     result is the rectangle table (16 bytes per ROI, one copy): the work list's shapes are needed on the host.
     Returns ``(frames uint8 [n][H][W], rects [[(x0, y0, x1, y1), ...] per frame], flows float32 [n-1][H][W][2])`` -- torch
-    CUDA tensors and the host-side rectangle lists; ``flows[k]`` is zero outside the ROIs of frame k+1."""
+    CUDA tensors and the host-side rectangle lists; ``flows[k]`` is zero outside the ROIs of the gating frame."""
     import time
 
     import torch
@@ -103,6 +119,9 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
     if n_frames < 2:
         raise ValueError("the stream is shorter than two snapshots")
     rows, cols = H // cfg.MEMSIZE, W // cfg.MEMSIZE
+    if rows > 64 or cols > 64:
+        raise ValueError(f"gating map {rows}x{cols}: the device gating kernel takes maps up to 64x64 cells (use events_to_rois_host "
+                         "+ farneback_pairs for finer grids)")
     frames = torch.empty((n_frames, H, W), dtype=torch.uint8, device=dev)
     cur = torch.empty((n_frames, rows, cols), dtype=torch.float64, device=dev)
     flows = torch.empty((n_frames - 1, H, W, 2), dtype=torch.float32, device=dev)   # zero-filled by the flow call
@@ -116,9 +135,14 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
             acc.block_current_dev(cfg.MEMSIZE, cur[k])
         counts, rtab = gating.roi_from_surface_dev(cur, n_frames, (rows, cols), (H, W), cfg, max_rects=max_rects, ctx=ctx)
         ctx.synchronize()
+        most = int(counts.max().item())
+        if most > max_rects:   # more components than the table holds: one more (tiny) gating launch with room for all
+            counts, rtab = gating.roi_from_surface_dev(cur, n_frames, (rows, cols), (H, W), cfg, max_rects=most, ctx=ctx)
+            ctx.synchronize()
         t1 = time.perf_counter()
         # crop -> flow -> paste of every ROI of every pair: one native call builds the work list from the rectangle table
-        n_calls, n_pixels = farneback_roi_sequence_dev(frames, counts, rtab, flows, cfg.farneback_params, ctx=ctx)
+        n_calls, n_pixels = farneback_roi_sequence_dev(frames, counts, rtab, flows, cfg.farneback_params,
+                                                       gate_frame=0 if cfg.bug_compatible else 1, ctx=ctx)
         ctx.synchronize()
         t2 = time.perf_counter()
         rects = gating.rects_to_host(counts, rtab, ctx=ctx)

@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound(nsof_lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/nsof.h but not exported by libnsof.so"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes SIGNATURES out of sync with include/nsof.h"
-    assert lib.nsof_abi_version() == 2
+    assert lib.nsof_abi_version() == 3
     assert [lib.nsof_kernel_name(i) for i in range(_lib.K_COUNT)] == [b"prep", b"polyexp", b"flow_upsample",
                                                                      b"update_matrices", b"blur_solve",
                                                                      b"accum_update", b"iterate", b"mask_pack",

@@ -324,6 +324,19 @@ def test_events_to_rois_device_path_equals_host_path(nsof_lib, ctx):
             want = rb if flag == 1 else ([(min(r[0] for r in rb), min(r[1] for r in rb), max(r[2] for r in rb), max(r[3] for r in rb))] if rb else [])
             assert ra == want
         assert any(len(r) for _, r in a)
+        # a table too small for a map's components is grown by one more (tiny) gating launch, not an error
+        a1 = pipeline.events_to_rois(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5, snapshot_every=40, ctx=ctx, max_rects=1)
+        assert [r for _, r in a1] == [r for _, r in a]
+    # a gating grid beyond the kernel's 64 x 64 cells (MEMSIZE 4 -> 60 x 80) takes the host mirror, same contract
+    for flag in (1, 2):
+        cfg = gating.GatingConfig(MEMSIZE=4, EXTEND_HEIGHT_UPPER=2, EXTEND_HEIGHT_LOWER=2, EXTEND_WIDTH_LEFT=2,
+                                  EXTEND_WIDTH_RIGHT=2, THRES=240, FLAG=flag, farneback_params=nsof_lib.farneback.PARAMS_A)
+        a = pipeline.events_to_rois(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5, snapshot_every=40, ctx=ctx)
+        b = pipeline.events_to_rois_host(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5, snapshot_every=40, ctx=ctx)
+        assert len(a) == len(b) == 4 and a[0][0].shape == (60, 80)
+        for (ga, ra), (gb, rb) in zip(a, b):
+            assert np.array_equal(ga, gb)
+            assert ra == (rb if flag == 1 else ([(min(r[0] for r in rb), min(r[1] for r in rb), max(r[2] for r in rb), max(r[3] for r in rb))] if rb else []))
 
 
 @pytest.mark.gpu
@@ -344,9 +357,11 @@ def test_config3_roi_flow_pipeline_vs_oracle_chain(nsof_lib, ctx, oracle):
         ref_frames.append((np.float32(255.0) * w).astype(np.uint8))
         ref_cur.append(pipeline.surface_to_block_current(oracle.accum_resistance(w), 20))
     some_overlap = False
-    for flag in (1, 2):
+    for flag, compat in ((1, True), (2, True), (1, False), (2, False)):
+        # which map gates pair (k, k+1): the scripts' (memimg2 := memimg1 -> frame k) or opticalFlow3D's as written (frame k+1)
         cfg = gating.GatingConfig(MEMSIZE=20, EXTEND_HEIGHT_UPPER=10, EXTEND_HEIGHT_LOWER=10, EXTEND_WIDTH_LEFT=10,
-                                  EXTEND_WIDTH_RIGHT=10, THRES=240, FLAG=flag, farneback_params=PARAMS_B)
+                                  EXTEND_WIDTH_RIGHT=10, THRES=240, FLAG=flag, farneback_params=PARAMS_B, bug_compatible=compat)
+        gi = 0 if compat else 1
         tm = {}
         frames, rects, flows = pipeline.events_to_roi_flows(x, y, p, t, (H, W), cfg, slice_us=1000, silent_v=0.5,
                                                             snapshot_every=every, ctx=ctx, timings=tm)
@@ -364,12 +379,12 @@ def test_config3_roi_flow_pipeline_vs_oracle_chain(nsof_lib, ctx, oracle):
         for k in range(3):
             canvas = np.zeros((H, W, 2), np.float32)
             done = []
-            for (x0, y0, x1, y1) in rects[k + 1]:
+            for (x0, y0, x1, y1) in rects[k + gi]:
                 canvas[y0:y1, x0:x1] = oracle.farneback(np.ascontiguousarray(ref_frames[k][y0:y1, x0:x1]),
                                                         np.ascontiguousarray(ref_frames[k + 1][y0:y1, x0:x1]), *pb)
                 some_overlap |= any(x0 < b[2] and b[0] < x1 and y0 < b[3] and b[1] < y1 for b in done)
                 done.append((x0, y0, x1, y1))
-            assert np.array_equal(gfl[k], canvas), (flag, k, float(np.abs(gfl[k] - canvas).max()))
+            assert np.array_equal(gfl[k], canvas), (flag, compat, k, float(np.abs(gfl[k] - canvas).max()))
         assert any(len(r) for r in rects[1:])
 
 
@@ -386,21 +401,21 @@ def test_roi_sequence_call_empty_tables_and_errors(nsof_lib, ctx):
     rects = torch.zeros((3, 4, 4), dtype=torch.int32, device=dev)
     flows = torch.full((2, 200, 300, 2), 7.0, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    assert nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx) == (0, 0)
+    assert nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, gate_frame=1, ctx=ctx) == (0, 0)
     ctx.synchronize()
     assert float(flows.abs().max().item()) == 0.0
     counts[1] = 9
     with pytest.raises(nsof_lib.NsofError, match="rectangles"):
-        nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+        nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, gate_frame=1, ctx=ctx)
     counts[1] = 1
     rects[1, 0] = torch.tensor([10, 10, 400, 100], dtype=torch.int32)
     with pytest.raises(nsof_lib.NsofError, match="leaves"):
-        nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+        nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, gate_frame=1, ctx=ctx)
     # an overlapping pair of rectangles is pasted in order: the second one wins where they overlap
     counts[1] = 2
     rects[1, 0] = torch.tensor([20, 30, 180, 150], dtype=torch.int32)
     rects[1, 1] = torch.tensor([100, 60, 280, 190], dtype=torch.int32)
-    n, px = nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, ctx=ctx)
+    n, px = nsof_lib.farneback_roi_sequence_dev(frames, counts, rects, flows, nsof_lib.farneback.PARAMS_A, gate_frame=1, ctx=ctx)
     ctx.synchronize()
     assert (n, px) == (2, 160 * 120 + 180 * 130)
     got = flows[0].cpu().numpy()
