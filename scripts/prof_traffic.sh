@@ -44,13 +44,13 @@ for k, v in acc.items():
         continue
     med = lambda a: sorted(a)[len(a) // 2]
     fk, wk = med(v["FETCH_SIZE"]), med(v["WRITE_SIZE"])
-    # the x2 belongs to 16-B-per-lane reads only (guide: "other access widths are uncalibrated").  k_prep_same3_vec reads one
-    # dword per lane; doubled, its fetch would be 2.24x the source image although each wave issues loads for exactly 10 source
-    # rows per 8 it writes (1.25x) -- more than the kernel can request.  Undoubled it is 1.12x: 10 / 8 less what the L2 absorbs.
-    fmul = 1 if k == "k_prep_same3_vec" else 2
+    # measured multiplier (scripts/fetch_calib.sh -> profiles/r04_fetch_calibration.json): 2.0 for 4-, 8- and 16-byte-per-lane
+    # streaming reads alike, and 2 x FETCH_SIZE = 1.0001 x the frame bytes for the level-0 pyramid kernel's own read pattern
+    fmul = 2
     hbm = (fmul * fk + wk) * 1024
     out["kernels"][names[k]] = {"kernel": k, "fetch_kb": fk, "write_kb": wk, "algorithmic_bytes": alg[k],
-                                "hbm_bytes": int(hbm), "traffic_over_algorithmic": round(hbm / alg[k], 4)}
+                                "hbm_bytes": int(hbm), "traffic_over_algorithmic": round(hbm / alg[k], 4), "fetch_multiplier": fmul,
+                                "fetch_multiplier_basis": "measured: scripts/fetch_calib.sh (profiles/r04_fetch_calibration.json)"}
 json.dump(out, open(f"{repo}/gpurun_out/hbm_traffic_{tag}.json", "w"), indent=1)
 print(json.dumps(out["kernels"]))
 PY

@@ -37,7 +37,7 @@ out = {"_doc": "HBM bytes per launch from rocprofv3 PMC over bench.py's OWN laun
                "/opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE reports half the bytes of wide coalesced streaming reads, "
                "so it is doubled; WRITE_SIZE is exact for 16-B streaming stores.  bench.py multiplies its algorithmic "
                "bytes per launch by traffic_over_algorithmic and labels the result as an estimate.",
-       "round": 3, "kernels": {}}
+       "round": 4, "kernels": {}}
 for name, key in (("iterate", "roofline"), ("polyexp", "roofline_polyexp")):
     v = acc.get(name)
     if not v or not v["FETCH_SIZE"] or not v["WRITE_SIZE"] or not line.get(key):
@@ -48,7 +48,8 @@ for name, key in (("iterate", "roofline"), ("polyexp", "roofline_polyexp")):
     alg = line[key]["algorithmic_bytes_per_launch"]
     out["kernels"][name] = {"launches_counted": len(v["FETCH_SIZE"]), "fetch_kb_per_launch": round(fk, 1),
                             "write_kb_per_launch": round(wk, 1), "algorithmic_bytes_per_launch": alg,
-                            "hbm_bytes_per_launch": int(hbm), "traffic_over_algorithmic": round(hbm / alg, 4)}
+                            "hbm_bytes_per_launch": int(hbm), "traffic_over_algorithmic": round(hbm / alg, 4), "fetch_multiplier": 2.0,
+                            "fetch_multiplier_basis": "measured: scripts/fetch_calib.sh (profiles/r04_fetch_calibration.json)"}
 json.dump(out, open(f"{repo}/gpurun_out/hbm_traffic_bench_{tag}.json", "w"), indent=1)
 print(json.dumps(out["kernels"]))
 PY
