@@ -597,6 +597,91 @@ __global__ __launch_bounds__(256) void k_surface_gray(const float* __restrict__ 
     out[(ptrdiff_t)y * stride + x] = surface_gray_one(w[(size_t)y * W + x], neg_lam, mode);
 }
 
+// ---- surface frames as copy + patch (round 4) ---------------------------------------------------------------------------
+// With the silent voltage in the dead zone a pixel without events keeps its state bit for bit, so the 8-bit frame of interval
+// k differs from that of interval k-1 only at the pixels the interval's events touch (0.4 % of a 3840x2160 sensor at 1 M
+// events/s and 33 ms per frame).  The every-pixel pass moves 17 B/px per interval to find that out; here an interval is
+//   A  k_frames_scatter_copy   frames[k] = frames[k-1] (2 B/px) while the interval's events are scattered into the per-pixel
+//                              slice masks (one 64-bit word: up to 64 slices) and the compact list of touched pixels
+//   B  k_frames_update_patch   the touched pixels replay their slices in order (the update of k_update_sparse), store w and
+//                              overwrite their byte of frames[k]
+// -- same states, same frames (tests/test_accum_gpu.py::test_run_frames_copy_patch_equals_dense_frames).
+__global__ __launch_bounds__(256) void k_frames_scatter_copy(const uint8_t* __restrict__ prev, uint8_t* __restrict__ cur, int W, int H,
+                                                              long long row_stride, const short* __restrict__ x,
+                                                              const short* __restrict__ y, long long ev0, long long n_ev,
+                                                              const long long* __restrict__ bounds, int n_sl,
+                                                              unsigned long long* mask64, unsigned* list, unsigned* count)
+{
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nthreads = (long long)gridDim.x * 256;
+    // the events of the interval FIRST (their atomics' latency then overlaps the copy; whole waves take part: the list append
+    // is aggregated per wave)
+    const long long n_ev_pad = (n_ev + 63) & ~63ll;
+    for (long long i = tid; i < n_ev_pad; i += nthreads) {
+        const bool live = i < n_ev;
+        const long long e = ev0 + (live ? i : 0);
+        int lo = 0, hi = n_sl;  // largest s with bounds[s] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (bounds[mid] <= e) lo = mid; else hi = mid;
+        }
+        // ONE 64-bit slice mask per pixel: a pixel enters the list exactly once per interval (its first touch), so no two
+        // threads of the update ever hold the same pixel
+        const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
+        const unsigned long long old = live ? atomicOr(&mask64[pix], 1ull << lo) : 1ull;
+        const bool first = live && old == 0;
+        const unsigned long long b = __ballot(first);
+        if (b) {
+            const int lane = threadIdx.x & 63, leader = __ffsll((long long)b) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(b));
+            base = __shfl(base, leader);
+            if (first) list[base + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = pix;
+        }
+    }
+    // ... then this thread's share of the copy
+    if (prev) {
+        if (row_stride == W && (((size_t)W * H) & 15) == 0 && ((reinterpret_cast<uintptr_t>(prev) | reinterpret_cast<uintptr_t>(cur)) & 15) == 0) {
+            const long long n16 = (long long)W * H / 16;
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            const u4v* s4 = reinterpret_cast<const u4v*>(prev);
+            u4v* d4 = reinterpret_cast<u4v*>(cur);
+#ifdef NSOF_ACC_COPY_PLAIN
+            for (long long i = tid; i < n16; i += nthreads) d4[i] = s4[i];
+#else
+            for (long long i = tid; i < n16; i += nthreads) __builtin_nontemporal_store(s4[i], d4 + i);
+#endif
+        } else {
+            const long long n = (long long)W * H;
+            for (long long i = tid; i < n; i += nthreads) {
+                const long long yy = i / W, xx = i - yy * W;
+                cur[yy * row_stride + xx] = prev[yy * row_stride + xx];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_frames_update_patch(float* __restrict__ w, unsigned long long* __restrict__ mask64,
+                                                              const unsigned* __restrict__ list,
+                                                              const unsigned* __restrict__ count, float v_act, unsigned* zero_next,
+                                                              uint8_t* __restrict__ frame, int W, long long row_stride,
+                                                              float neg_lam, int mode)
+{
+    const unsigned n = *count;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0;   // the NEXT interval's list counter (other parity)
+    const Drive da = drive_of(v_act);
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const unsigned pix = list[i];
+        unsigned long long m = mask64[pix];
+        mask64[pix] = 0;
+        float ww = w[pix];
+        for (; m; m >>= 1)
+            if (m & 1ull) ww = update_drive(ww, da);
+        w[pix] = ww;
+        const unsigned yy = pix / (unsigned)W, xx = pix - yy * (unsigned)W;
+        frame[(long long)yy * row_stride + xx] = surface_gray_one(ww, neg_lam, mode);
+    }
+}
+
 // bincount_2d (event_mem_sim.py:100-104): events per pixel.
 __global__ __launch_bounds__(256) void k_bincount(const short* __restrict__ x, const short* __restrict__ y, size_t n,
                                                    int W, int* __restrict__ counts)
@@ -623,6 +708,7 @@ struct nsof_accum {
     long long* next_ok[2] = {nullptr, nullptr};
     unsigned* mask[2] = {nullptr, nullptr};
     unsigned* mask_hi = nullptr;   // slices 32..63 of a dense scheme-1 group (allocated on first use, kept zero between groups)
+    unsigned long long* mask64 = nullptr;   // nsof_accum_run_frames (copy + patch): one 64-bit slice mask per pixel
     unsigned* list[2] = {nullptr, nullptr};
     size_t list_cap = 0;
     unsigned* count = nullptr;  // [2]
@@ -668,7 +754,7 @@ extern "C" void nsof_accum_destroy(nsof_accum* a)
     for (int i = 0; i < 2; i++) {
         hipFree(a->w[i]); hipFree(a->next_ok[i]); hipFree(a->mask[i]); hipFree(a->list[i]); hipFree(a->snap[i]);
     }
-    hipFree(a->mask_hi); hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
+    hipFree(a->mask_hi); hipFree(a->mask64); hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
     hipFree(a->d_slices); hipFree(a->d_groups); hipFree(a->d_gi);
     if (a->graph) hipGraphExecDestroy(a->graph);
     delete a;
@@ -1138,6 +1224,70 @@ extern "C" int nsof_accum_run_surface(nsof_accum* a, int64_t first_slice, int64_
     if (!a || !d_out || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W || mode < 0 || mode > 1) return NSOF_EINVAL;
     const SurfOut so{d_out, (long long)row_stride, a->W, (float)(-std::log(ROFF / RON)), mode};
     return accum_advance(a, first_slice, n_slices, 0, &so, which);
+}
+
+// n_frames consecutive intervals of `every` slices, the surface after each into d_frames[k] (k-th frame at + k * frame_stride
+// bytes).  Scheme 1 with the silent voltage in the dead zone and no forced every-pixel pass: frames as copy + patch (above),
+// two small launches per interval issued from this one call; otherwise n_frames x nsof_accum_run_surface.
+extern "C" int nsof_accum_run_frames(nsof_accum* a, int64_t first_slice, int64_t n_frames, int64_t every, int which, int mode,
+                                     uint8_t* d_frames, ptrdiff_t row_stride, ptrdiff_t frame_stride)
+{
+    if (!a || !d_frames || which < 0 || which > (a->split ? 1 : 0) || row_stride < a->W || mode < 0 || mode > 1 || n_frames < 0 ||
+        every < 1 || frame_stride < 0)
+        return NSOF_EINVAL;
+    nsof_ctx* ctx = a->ctx;
+    if (n_frames == 0) return NSOF_OK;
+    if (first_slice < 0 || (size_t)(first_slice + n_frames * every + 1) > a->h_rel.size())
+        return nsof_set_error(ctx, NSOF_EINVAL, "slices [%lld, %lld) outside the staged stream", (long long)first_slice,
+                              (long long)(first_slice + n_frames * every));
+    const bool dead_zone = !(a->silent_v < VOFF) && !(a->silent_v > VON);
+    const float neg_lam = (float)(-std::log(ROFF / RON));
+    if (!(a->scheme == 1 && dead_zone && a->force_dense <= 0 && every <= 2 * MAX_GROUP)) {
+        for (int64_t k = 0; k < n_frames; k++) {
+            const SurfOut so{d_frames + k * frame_stride, (long long)row_stride, a->W, neg_lam, mode};
+            if (int rc = accum_advance(a, first_slice + k * every, every, 0, &so, which)) return rc;
+        }
+        return NSOF_OK;
+    }
+    NSOF_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (!a->mask64) {   // per-pixel 64-bit slice masks of this path (kept zero between intervals)
+        if ((rc = accum_alloc(ctx, (void**)&a->mask64, a->npx * sizeof(unsigned long long)))) return rc;
+        NSOF_HIP(ctx, hipMemsetAsync(a->mask64, 0, a->npx * sizeof(unsigned long long), ctx->stream));
+    }
+    const std::vector<long long>& rel = a->h_rel;
+    NSOF_HIP(ctx, hipMemsetAsync(a->count, 0, 4 * sizeof(unsigned), ctx->stream));
+    int par = 0;
+#ifndef NSOF_ACC_COPY_BLOCKS
+#define NSOF_ACC_COPY_BLOCKS 4096
+#endif
+    const unsigned copy_blocks = (unsigned)std::min<size_t>(NSOF_ACC_COPY_BLOCKS, (a->npx / 16 + 255) / 256 + 1);
+    for (int64_t k = 0; k < n_frames; k++) {
+        const int64_t s0 = first_slice + k * every;
+        const long long ge0 = rel[s0], gn = rel[s0 + every] - ge0;
+        unsigned* const cnt = a->count + 2 * par;
+        unsigned* const cnt_next = a->count + 2 * (par ^ 1);
+        uint8_t* const cur = d_frames + k * frame_stride;
+        const uint8_t* const prev = k > 0 ? d_frames + (k - 1) * frame_stride : nullptr;
+        nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+        if (prev || gn > 0) {
+            const unsigned blocks = prev ? copy_blocks : (unsigned)((gn + 255) / 256);
+            hipLaunchKernelGGL(k_frames_scatter_copy, dim3(blocks), dim3(256), 0, ctx->stream, prev, cur, a->W, a->H,
+                               (long long)row_stride, a->dx, a->dy, ge0, gn, a->dbounds + s0, (int)every, a->mask64, a->list[0], cnt);
+        }
+        // (launched for an empty interval as well: it zeroes the next interval's counter)
+        hipLaunchKernelGGL(k_frames_update_patch, dim3(grid_for((size_t)std::max<long long>(gn, 1), 1024)), dim3(256), 0, ctx->stream,
+                           a->w[0], a->mask64, a->list[0], cnt, a->active_v, cnt_next, cur, a->W,
+                           (long long)row_stride, neg_lam, mode);
+        NSOF_HIP(ctx, hipGetLastError());
+        if (k == 0) {   // the call's first frame has no predecessor to copy: one pass over the array
+            const SurfOut so{cur, (long long)row_stride, a->W, neg_lam, mode};
+            if ((rc = accum_surface(a, which, so))) return rc;
+        }
+        a->slice_counter += every;
+        par ^= 1;
+    }
+    return NSOF_OK;
 }
 
 // Checkpoint / resume: the whole state of one array is w (float32 [H][W]), its refractory map (int64 [H][W],

@@ -206,9 +206,15 @@ class Accumulator:
                        "accum_run_surface")
 
     def run_frames(self, first_slice, n_frames, every, frames, which=0, mode="state"):
-        """``n_frames`` intervals of ``every`` slices, the surface after each into ``frames[k]`` (uint8 CUDA tensor [n][H][W])."""
-        for k in range(n_frames):
-            self.run_surface(first_slice + k * every, every, frames[k], which=which, row_stride=int(frames.stride(1)), mode=mode)
+        """``n_frames`` intervals of ``every`` slices, the surface after each into ``frames[k]`` (uint8 CUDA tensor [n][H][W]):
+        one call (``nsof_accum_run_frames``).  Scheme 1 with ``silent_v`` in the dead zone (and ``dense`` not forced): frame
+        k is frame k-1 copied and patched at the event pixels -- byte-identical to ``run_surface`` per interval."""
+        if int(frames.stride(2)) != 1:
+            raise NsofValueError("frames: pixel stride must be 1")
+        self.ctx.check(self.ctx._lib.nsof_accum_run_frames(self._p, int(first_slice), int(n_frames), int(every), which,
+                                                           {"current": 0, "state": 1}[mode], dev_ptr(frames),
+                                                           int(frames.stride(1)), int(frames.stride(0)) if n_frames > 1 else 0),
+                       "accum_run_frames")
 
     def surface_u8(self, d_out, which=0, row_stride=None, mode="state"):
         """The current surface as an 8-bit frame written to DEVICE memory (torch uint8 tensor / address).

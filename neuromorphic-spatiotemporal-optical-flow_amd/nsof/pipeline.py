@@ -154,14 +154,16 @@ def events_to_roi_flows(x, y, p, t, sensor_hw, cfg, slice_us=1000, active_v=-6.0
 
 
 def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, active_v=-6.0, silent_v=0.0,
-                            snapshot_every=33, dense=True, ctx=None, timings=None):
+                            snapshot_every=33, dense=None, ctx=None, timings=None):
     """BASELINE config 5 as one device-resident pipeline: event stream -> dense scheme-1 accumulator update of every
     slice -> every ``snapshot_every`` slices the surface as an 8-bit frame (``Accumulator.surface_u8``, mode "state":
     uint8(255 * w) -- the reference's current -> gray map saturates for the simulator's w >= 0.5 and the reference has
     no surface -> frame step of its own) -> Farneback flow between consecutive surface frames
     (``farneback_sequence``: every frame's pyramid and expansion computed once).  Events are uploaded once; frames and
     flow never leave HBM.  Returns ``(frames uint8 [n][H][W], flows float32 [n-1][H][W][2])`` as torch CUDA tensors.
-    ``timings`` (a dict) receives the wall time of the two stages."""
+    ``dense``: None (default) = the accumulator picks (with ``silent_v`` in the dead zone: frames as copy + patch of the
+    previous one, ``nsof_accum_run_frames``), True = the every-pixel pass per interval (the roofline run), False = the
+    event-pixel update.  Same frames either way.  ``timings`` (a dict) receives the wall time of the two stages."""
     import time
 
     import torch
@@ -198,7 +200,7 @@ def events_to_flow_sequence(x, y, p, t, sensor_hw, params=None, slice_us=1000, a
 
 
 def events_to_flow_sequence_sharded(x, y, p, t, sensor_hw, params=None, slice_us=1000, active_v=-6.0, silent_v=0.0,
-                                    snapshot_every=33, dense=True, ctx=None, stats=None):
+                                    snapshot_every=33, dense=None, ctx=None, stats=None):
     """``events_to_flow_sequence`` over the ranks of the current process group (one GPU each): accumulator row bands,
     all-gather of the 8-bit surface frames, contiguous shards of the frame pairs (``nsof.dist.events_to_flow_sharded``
     with the GPU accumulator and ``farneback_sequence`` as the two stages).  Returns ``((lo, hi), frames, flows_local)``

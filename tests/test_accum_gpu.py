@@ -569,6 +569,45 @@ def test_run_surface_equals_run_then_surface(nsof_lib, ctx):
 
 
 @pytest.mark.gpu
+def test_run_frames_copy_patch_equals_dense_frames(nsof_lib, ctx, oracle):
+    """nsof_accum_run_frames: with the silent voltage in the dead zone a frame is its predecessor copied and patched at the
+    event pixels (two small launches per interval) -- frames and final state byte-identical to the every-pixel pass per
+    interval (dense=True takes n x run_surface), both surface modes, intervals of 33 / 7 / 64 slices, dense and strided frame
+    tensors, a second call that continues the stream; the state against the CPU oracle; a silent voltage OUTSIDE the dead
+    zone takes the generic path through the same entry."""
+    import torch
+    from nsof import synth
+    from nsof.accumulator import Accumulator, slice_index_array
+    dev = torch.device("cuda", ctx.device)
+    for (H, W, every, pad, silent) in [(120, 160, 33, 0, 0.0), (77, 131, 7, 5, 0.0), (96, 128, 64, 0, 0.05), (90, 202, 33, 0, 0.5)]:
+        x, y, p, t = synth.make_events(9, W, H, 9000, 200_000, box=(20, 16))
+        idx = slice_index_array(t, 1000)
+        n_fr = (len(idx) - 1) // every
+        assert n_fr >= 3
+        for mode in ("state", "current"):
+            got = {}
+            for dense in (True, None):
+                acc = Accumulator(H, W, 1, "split", -6.0, silent, ctx=ctx, dense=dense)
+                try:
+                    acc.set_events(x, y, p, t, idx)
+                    buf = torch.zeros((n_fr, H, W + pad), dtype=torch.uint8, device=dev)
+                    torch.cuda.synchronize()
+                    acc.run_frames(0, 2, every, buf[:2, :, :W], mode=mode)                  # two calls: the second continues
+                    acc.run_frames(2 * every, n_fr - 2, every, buf[2:, :, :W], mode=mode)
+                    ctx.synchronize()
+                    got[dense] = (buf.cpu().numpy(), acc.w())
+                finally:
+                    acc.close()
+            assert np.array_equal(got[None][0], got[True][0]), (H, W, every, silent, mode)
+            assert np.array_equal(got[None][1], got[True][1])
+            assert got[None][0][:, :, :W].any() and not got[None][0][:, :, W:].any()
+            if mode == "state":   # (the current -> gray map saturates at 255 for w >= 0.42: those frames are constant)
+                assert len({got[None][0][k].tobytes() for k in range(n_fr)}) > 1          # the frames do change
+        _, w_ref = oracle.accum_slices_per_s(x, y, t, H, W, 1000, -6.0, silent, n_slices=n_fr * every, n_threads=2)
+        assert np.abs(got[None][1] - w_ref).max() <= 5e-7
+
+
+@pytest.mark.gpu
 def test_dense_groups_of_64_slices(nsof_lib, ctx, oracle):
     """The dense scheme-1 update fuses up to 64 slices per pass (two mask words per pixel): runs whose groups exceed 32
     slices equal the event-pixel path bit for bit (silent voltage in the dead zone) and the oracle within the usual
