@@ -254,6 +254,9 @@ extern "C" void nsof_destroy(nsof_ctx* ctx)
     if (ctx->het_d) hipFree(ctx->het_d);
     if (ctx->x_carry) hipFree(ctx->x_carry);
     if (ctx->roi_tmp) hipFree(ctx->roi_tmp);
+    if (ctx->paste_h) hipHostFree(ctx->paste_h);
+    if (ctx->paste_d) hipFree(ctx->paste_d);
+    if (ctx->paste_ev) hipEventDestroy(ctx->paste_ev);
     if (ctx->x_sync) hipFree(ctx->x_sync);
     for (auto ev : ctx->het_ev)
         if (ev) hipEventDestroy(ev);

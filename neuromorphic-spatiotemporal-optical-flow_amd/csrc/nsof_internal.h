@@ -62,6 +62,11 @@ struct nsof_ctx {
     // private flow buffers of ROI crops that overlap an earlier crop of the same frame pair (nsof_farneback_u8_roi_sequence_dev)
     void* roi_tmp = nullptr;
     size_t roi_tmp_bytes = 0;
+    // ... and the table of their ordered pastes (pinned host copy, device copy, the event after its last upload)
+    void* paste_h = nullptr;
+    void* paste_d = nullptr;
+    size_t paste_bytes = 0;
+    hipEvent_t paste_ev = nullptr;
     unsigned long long* x_carry = nullptr;
     size_t x_carry_bytes = 0;
     unsigned* x_sync = nullptr;
