@@ -641,7 +641,9 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         // + 20 / 40 B/px of matrices / column sums in the unfused / exact forms) would not fit the device's free memory is run in chunks of as many pairs as do
         // fit -- same kernels on sub-ranges of the same buffers, so the result does not depend on the chunking.
         // NSOF_MAX_PAIRS caps the chunk by hand (tests).
-        const size_t per_pair = (size_t)width * height * (4 * 2 + 20 * 2 + 8 + 20 + (exact && !exact_x ? 40 : 0) + (exact_lat ? 60 : 0)) + 4096;
+        // (the latency schedule of small batches keeps the level images and expansions of EVERY level: at most levels + 1 times those terms)
+        const size_t per_pair = (size_t)width * height * ((4 * 2 + 20 * 2) * (exact_lat ? (size_t)levels + 1 : 1) + 8 + 20 +
+                                                          (exact && !exact_x ? 40 : 0) + (exact_lat ? 60 : 0)) + 4096;
         size_t fit = ctx->ws_bytes / per_pair;   // what the workspace already holds needs no query (lone calls stay cheap)
         if ((size_t)n_pairs > fit) {
             size_t free_b = 0, total_b = 0;
@@ -796,6 +798,103 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     }
 #endif
 
+    // prev and next frames of a batch that lie back to back (the host-pointer entry stages a lone pair that way) are one
+    // array of 2 B images: one pyramid launch per level instead of two (a lone call's launches have a ~5 us floor each)
+    const bool prep_merged = !sequence && d_next == d_prev + (ptrdiff_t)n_pairs * pair_stride;
+    auto prep_level = [&](int wk, int hk, const nsof_blur_taps& bt, float* I) -> int {
+        const size_t nk = (size_t)wk * hk;
+        if (sequence || prep_merged)
+            return NSOF_PYR_SEL(ctx, nsof_launch_prep, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, bt, I);
+        for (int i = 0; i < 2; i++)
+            if (int r = NSOF_PYR_SEL(ctx, nsof_launch_prep, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width, height,
+                                     wk, hk, bt, I + (size_t)i * B * nk))
+                return r;
+        return NSOF_OK;
+    };
+
+    // ---- small batches (the three-kernel exact form): the latency schedule ---------------------------------------------
+    // A lone call is a chain of ~50 launches that each use a fraction of the chip and cost >= ~5 us (profiles/
+    // r03_lone_call_timeline.txt: 762 us at 1080p, a third of it in the two coarsest levels).  Only the FLOW couples the
+    // levels; pyramid level and polynomial expansion of every level depend on the input frames alone.  So they move to a
+    // side stream (levels L-1 .. 0, into per-level buffers) and run next to the iterations of the coarser levels on the
+    // main stream; an event per level hands the expansion over.  Same kernels, same arguments, same bits.
+    if (exact_lat && fused && L >= 1 && iterations > 0) {
+        std::vector<size_t> offI(L + 1), offR(L + 1);
+        size_t totI = 0, totR = 0;
+        for (int k = 0; k <= L; k++) {
+            int wk, hk;
+            nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, nullptr, nullptr);
+            offI[k] = totI; offR[k] = totR;
+            totI += align_up(n_img * (size_t)wk * hk * 4, 256);
+            totR += align_up(n_img * 5 * (size_t)wk * hk * 4, 256);
+        }
+        if ((rc = nsof_ws_reserve(ctx, &ctx->ws, &ctx->ws_bytes, totI + totR + szS + szM + szV))) return rc;
+        base = (char*)ctx->ws;
+        float* dS2 = (float*)(base + totI + totR);
+        float* dM2 = (float*)(base + totI + totR + szS);
+        double* dV2 = (double*)(base + totI + totR + szS + szM);
+        float* fl[2] = {d_flow, dS2};
+        int c = (L * (1 + iterations) + iterations) & 1;
+        if (!ctx->side) NSOF_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        while (ctx->ov_events.size() < (size_t)(L + 2)) {
+            hipEvent_t ev;
+            NSOF_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->ov_events.push_back(ev);
+        }
+        struct StreamSwap {
+            nsof_ctx* cx; hipStream_t saved;
+            StreamSwap(nsof_ctx* cc, hipStream_t st) : cx(cc), saved(cc->stream) { cx->stream = st; }
+            ~StreamSwap() { cx->stream = saved; }
+        };
+        auto level_images = [&](int k) -> int {   // pyramid level + expansion of level k on the CURRENT ctx->stream
+            int wk, hk, ks;
+            double sg;
+            nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, &ks, &sg);
+            nsof_blur_taps bt;
+            if (int r = nsof_host_blur_taps(ks, sg, &bt))
+                return nsof_set_error(ctx, r, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
+            float* I = (float*)(base + offI[k]);
+            if (int r = prep_level(wk, hk, bt, I)) return r;
+            return nsof_launch_polyexp(ctx, (int)n_img, I, wk, hk, ptaps, (float*)(base + totI + offR[k]));
+        };
+        const hipStream_t mainS = ctx->stream, sideS = ctx->side;
+        NSOF_HIP(ctx, hipEventRecord(ctx->ov_events[L + 1], mainS));            // the frames are on the device; earlier calls are done
+        NSOF_HIP(ctx, hipStreamWaitEvent(sideS, ctx->ov_events[L + 1], 0));
+        if ((rc = level_images(L))) return rc;                                  // the coarsest level: needed first, main stream
+        {
+            StreamSwap sw(ctx, sideS);
+            for (int k = L - 1; k >= 0; k--) {
+                if ((rc = level_images(k))) return rc;
+                NSOF_HIP(ctx, hipEventRecord(ctx->ov_events[k], sideS));
+            }
+        }
+        int pw2 = 0, ph2 = 0;
+        for (int k = L; k >= 0; k--) {
+            int wk, hk;
+            nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, nullptr, nullptr);
+            const size_t nk = (size_t)wk * hk;
+            if (k == L) {
+                NSOF_HIP(ctx, hipMemsetAsync(fl[c], 0, B * nk * 8, mainS));
+            } else {
+                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample, n_pairs, fl[c], pw2, ph2, fl[c ^ 1], wk, hk, (float)(1. / pyr_scale))))
+                    return rc;
+                c ^= 1;
+                NSOF_HIP(ctx, hipStreamWaitEvent(mainS, ctx->ov_events[k], 0));   // this level's expansion is ready
+            }
+            const float* R0 = (const float*)(base + totI + offR[k]);
+            const float* R1 = R0 + (sequence ? (size_t)1 : B) * 5 * nk;
+            for (int it = 0; it < iterations; it++) {
+                if ((rc = nsof_launch_iterate_lat(ctx, n_pairs, R0, R1, 5 * nk, fl[c], fl[c ^ 1], wk, hk, winsize, dM2, dV2))) return rc;
+                c ^= 1;
+            }
+            pw2 = wk;
+            ph2 = hk;
+        }
+        if (fl[c] != d_flow)
+            NSOF_HIP(ctx, hipMemcpyAsync(d_flow, fl[c], B * n0 * 8, hipMemcpyDeviceToDevice, mainS));
+        return NSOF_OK;
+    }
+
     bool have_prev = false;
     int pw = 0, ph = 0;
     for (int k = L; k >= 0; k--) {
@@ -820,15 +919,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         }
         // image-major: dI [n_img][hk][wk], dR [n_img][5*hk*wk].  Pairs: all prev frames then all next frames
         // (R1 = R0 + B images); sequence: the frames in order (R1 = R0 + 1 image).
-        if (sequence) {
-            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep, (int)n_img, d_prev, row_stride, pair_stride, width, height, wk, hk, btaps, dI)))
-                return rc;
-        } else {
-            for (int i = 0; i < 2; i++)
-                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep, n_pairs, i == 0 ? d_prev : d_next, row_stride, pair_stride, width,
-                                           height, wk, hk, btaps, dI + (size_t)i * B * nk)))
-                    return rc;
-        }
+        if ((rc = prep_level(wk, hk, btaps, dI))) return rc;
         if ((rc = nsof_launch_polyexp(ctx, (int)n_img, dI, wk, hk, ptaps, dR))) return rc;
         const float* R0 = dR;
         const float* R1 = dR + (sequence ? (size_t)1 : B) * 5 * nk;
