@@ -624,7 +624,9 @@ def config5_leg(nsof, torch, local_rank):
         survey_bytes = 8.0 * npx * n_sl + 16.0 * n_ev
         fused_bytes = (n_sl / every) * (16.0 + 1.0) * npx + 4.0 * n_ev
         rate_dense = n_sl / tmd["accumulator_s"]
-        patch_bytes = (n_sl / every) * 2.0 * npx + 4.0 * n_ev + 13.0 * n_ev   # frame copied (1 + 1 B/px); per event: x, y read, mask + list + w + byte touched
+        # the tile walk: frames are write-only (1 B/px per frame), w is read and written once per run, an event is read twice
+        # (x, y: 4 B) by the bucketing pass and its 2-byte record written and read once
+        patch_bytes = (n_sl / every) * 1.0 * npx + 8.0 * npx + 12.0 * n_ev
         # parity + CPU rate on a bounded sample: the first k slices through the CPU oracle
         k = 20
         model, logical, physical, usable = O.host_cpu()
@@ -643,12 +645,13 @@ def config5_leg(nsof, torch, local_rank):
         out["accumulator"] = {
             "value": round(rate, 1), "unit": "slices/s", "workload": f"{W}x{H} sensor, 1 M events/s, 1 ms slices, scheme-1 "
             f"update of every slice + a surface frame every {every} slices; events uploaded once.  value = the default path "
-            "(silent voltage in the dead zone: a frame is its predecessor copied and patched at the event pixels, "
-            "nsof_accum_run_frames); dense_roofline_run = the every-pixel pass per interval (dense=True), same frames",
+            "(silent voltage in the dead zone: nsof_accum_run_frames as a tile-persistent walk -- a wave owns 1024 pixels for the "
+            "whole run, state / frame bytes / slice masks in LDS, frames write-only, two launches per run); "
+            "dense_roofline_run = the every-pixel pass per interval (dense=True), same frames",
             "frames_identical_to_dense_run": frames_same,
-            "copy_patch_bytes": {"bytes_per_slice": round(patch_bytes / n_sl), "achieved": round(patch_bytes / tm["accumulator_s"] / 1e9, 1),
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(patch_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3),
-                                 "note": "2 B/px per frame + the event pixels: two ~10 us launches per interval, launch / latency bound"},
+            "roofline_tile_walk_bytes": {"bytes_per_slice": round(patch_bytes / n_sl), "achieved": round(patch_bytes / tm["accumulator_s"] / 1e9, 1),
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(patch_bytes / tm["accumulator_s"] / 1e9 / HBM_PEAK_GBS, 3),
+                                         "note": "1 B/px per frame written + w once per run + 12 B per event: what this form has to move"},
             "dense_roofline_run": {"value": round(rate_dense, 1), "unit": "slices/s",
                                    "roofline_fused_bytes": {"bytes_per_slice": round(fused_bytes / n_sl),
                                                             "achieved": round(fused_bytes / tmd["accumulator_s"] / 1e9, 1), "peak": HBM_PEAK_GBS,

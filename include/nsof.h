@@ -298,10 +298,16 @@ int nsof_accum_run_surface(nsof_accum* a, int64_t first_slice, int64_t n_slices,
 /* n_frames consecutive intervals of `every` slices, the surface after each interval into d_frames + k * frame_stride (uint8
  * [H][row_stride] each) -- what n_frames calls of nsof_accum_run_surface give, byte for byte, issued from one call.  Scheme 1
  * with the silent voltage in the dead zone [voff, von] (no forced every-pixel pass, every <= 64): frame k is frame k-1 copied
- * (2 B/px) and patched at the pixels the interval's events touched, the state updated at those pixels only -- an interval
- * is two small launches instead of a 17 B/px pass.  Asynchronous on the context's stream. */
+ * (2 B/px) and patched at the pixels the interval's events touched, the state updated at those pixels only -- or, by
+ * default, the whole run as one tile-persistent walk (nsof_accum_set_frames_path).  Asynchronous on the context's stream. */
 int nsof_accum_run_frames(nsof_accum* acc, int64_t first_slice, int64_t n_frames, int64_t every, int which, int mode,
                           uint8_t* d_frames, ptrdiff_t row_stride, ptrdiff_t frame_stride);
+/* Which of its two event-driven forms nsof_accum_run_frames takes where both apply (same bytes): 0 (default) = the tile
+ * walk -- a wave owns 1024 consecutive pixels for the whole run (state, current frame bytes and slice masks in LDS), the
+ * run's events are bucketed by (interval, tile) first, frames are write-only: two launches per call; needs sensor width,
+ * row and frame strides that are multiples of 16 and a 16-byte aligned frame buffer -- 1 = copy + patch per interval (two
+ * launches per interval; what the tile walk falls back to, and its cross-check in the tests). */
+int nsof_accum_set_frames_path(nsof_accum* acc, int path);
 /* Checkpoint / resume (the reference persists only w_final, event_mem_sim.py:289-303): copy one array's state to /
  * from HOST memory -- w float32 [H][W], the refractory map int64 [H][W] (scheme 2; zeros otherwise) and the global
  * slice counter that times the snapshots.  NULL pointers are skipped. */

@@ -682,6 +682,173 @@ __global__ __launch_bounds__(256) void k_frames_update_patch(float* __restrict__
     }
 }
 
+// ---- surface frames by a tile-persistent walk (round 4) -------------------------------------------------------------
+// Pixels never interact, so nothing forces an interval to be a launch: a WAVE owns a tile of 1024 consecutive pixels for
+// the WHOLE run.  Its state (w, 4 KB), the 8-bit bytes of the current frame (1 KB) and a 64-bit slice mask per pixel (8 KB)
+// live in LDS; per interval it ORs the tile's events into the masks, lets one lane per touched pixel replay them
+// (atomicExch claims the mask), and streams the tile's 1 KB of frame k out -- frames are WRITE-ONLY (1 B/px per frame, no
+// read of the previous frame), the state is read and written once per run:
+//   k_tile_bucket   the run's events bucketed by (interval, tile): records of 16 bits (pixel in tile, slice in interval);
+//                   the order inside a bucket is irrelevant (scheme 1 applies the same drive once per distinct active slice)
+//   k_tile_frames   the walk
+// -- two launches per call.
+constexpr int TILE_PX = 1024, TILE_SHIFT = 10;
+
+// One workgroup per interval buckets that interval's events by tile: the events of interval k are the contiguous range
+// [bounds[k * every], bounds[(k + 1) * every]) of the time-sorted stream and their records fill exactly that range of recs,
+// so the counting sort is local -- histogram over the tiles in LDS, exclusive scan, fill through LDS cursors -- and no
+// global scan or global atomic is needed.  off[k * ntiles + t] = start of bucket (k, t) in recs; off[n_frames * ntiles] = n_ev.
+__global__ __launch_bounds__(1024) void k_tile_bucket(const short* __restrict__ x, const short* __restrict__ y, long long ev0,
+                                                       const long long* __restrict__ bounds, int every, int W, unsigned ntiles,
+                                                       unsigned* __restrict__ off, unsigned short* __restrict__ recs, int n_frames)
+{
+    extern __shared__ unsigned s_cnt[];           // [ntiles]
+    __shared__ long long s_b[65];                 // the interval's slice bounds (event indices)
+    __shared__ unsigned s_part[1024];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    for (unsigned t = tid; t < ntiles; t += 1024) s_cnt[t] = 0;
+    if (tid <= every) s_b[tid] = bounds[(size_t)k * every + tid];
+    __syncthreads();
+    const long long lo = s_b[0], hi = s_b[every];
+    const unsigned base = (unsigned)(lo - ev0);
+    auto rec_of = [&](long long e, unsigned& tile) -> unsigned {
+        int a = 0, b = every;                     // largest s with s_b[s] <= e
+        while (b - a > 1) {
+            const int mid = (a + b) >> 1;
+            if (s_b[mid] <= e) a = mid; else b = mid;
+        }
+        const unsigned pix = (unsigned)y[e] * (unsigned)W + (unsigned)x[e];
+        tile = pix >> TILE_SHIFT;
+        return (pix & (TILE_PX - 1)) | ((unsigned)a << TILE_SHIFT);
+    };
+    for (long long e = lo + tid; e < hi; e += 1024) {
+        unsigned tile;
+        (void)rec_of(e, tile);
+        atomicAdd(&s_cnt[tile], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the tiles: thread i owns tiles [i * per, (i + 1) * per)
+    const unsigned per = (ntiles + 1023) / 1024, t0 = tid * per, t1 = min(t0 + per, ntiles);
+    unsigned sum = 0;
+    for (unsigned t = t0; t < t1; t++) sum += s_cnt[t];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        const unsigned v = tid >= (int)d ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;
+    for (unsigned t = t0; t < t1; t++) {
+        const unsigned c = s_cnt[t];
+        off[(size_t)k * ntiles + t] = base + run;
+        s_cnt[t] = run;                           // the fill pass's cursor
+        run += c;
+    }
+    if (k == n_frames - 1 && tid == 0) off[(size_t)n_frames * ntiles] = (unsigned)(hi - ev0);
+    __syncthreads();
+    for (long long e = lo + tid; e < hi; e += 1024) {
+        unsigned tile;
+        const unsigned rec = rec_of(e, tile);
+        recs[base + atomicAdd(&s_cnt[tile], 1u)] = (unsigned short)rec;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_frames(float* __restrict__ w, size_t npx, int W, const unsigned* __restrict__ off,
+                                                      const unsigned short* __restrict__ recs, unsigned ntiles, int n_frames,
+                                                      float v_act, uint8_t* __restrict__ frames, long long row_stride,
+                                                      long long frame_stride, float neg_lam, int mode)
+{
+    __shared__ unsigned long long s_mask[4][TILE_PX];
+    __shared__ __attribute__((aligned(16))) float s_w[4][TILE_PX];
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[4][TILE_PX];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned tile = blockIdx.x * 4 + wv;
+    if (tile >= ntiles) return;                                   // wave-uniform; no block barrier below
+    unsigned long long* ml = s_mask[wv];
+    float* wl = s_w[wv];
+    uint8_t* bl = s_b[wv];
+    const size_t p0 = (size_t)tile * TILE_PX + (size_t)lane * 16;   // this lane's 16 pixels (one row: W % 16 == 0)
+    const bool live = p0 < npx;
+    const size_t yy = live ? p0 / (size_t)W : 0, xx = live ? p0 - yy * (size_t)W : 0;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        f4v v = live ? reinterpret_cast<const f4v*>(w + p0)[j] : (f4v){0.f, 0.f, 0.f, 0.f};
+        reinterpret_cast<f4v*>(wl + lane * 16)[j] = v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) bl[lane * 16 + 4 * j + q] = surface_gray_one(v[q], neg_lam, mode);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) ml[lane * 16 + j] = 0ull;
+    const Drive da = drive_of(v_act);
+    bool dirty = false;
+    for (int kb = 0; kb < n_frames; kb += 63) {
+        // the bucket bounds of up to 63 intervals of this tile, one per lane (lane i: the start of interval kb + i)
+        // (buckets are laid out interval-major: bucket (k, tile) = recs[off[k * ntiles + tile] .. off[k * ntiles + tile + 1]))
+        const int kn = min(63, n_frames - kb);
+        const unsigned mybeg = lane < kn ? off[(size_t)(kb + lane) * ntiles + tile] : 0u;
+        const unsigned myend = lane < kn ? off[(size_t)(kb + lane) * ntiles + tile + 1] : 0u;
+        // the first 64 records of the next PF intervals are in flight (a record load is ~1 us of L2 latency against ~0.15 us
+        // of work per interval)
+        constexpr int PF = 4;
+        unsigned rq[PF];
+#pragma unroll
+        for (int d = 0; d < PF; d++) {
+            const unsigned qb = d < kn ? __builtin_amdgcn_readlane(mybeg, d) : 0u, qe = d < kn ? __builtin_amdgcn_readlane(myend, d) : 0u;
+            rq[d] = qb + lane < qe ? recs[qb + lane] : 0xffffffffu;
+        }
+        for (int i0 = 0; i0 < kn; i0 += PF) {
+#pragma unroll
+          for (int d = 0; d < PF; d++) {
+            const int i = i0 + d;
+            if (i >= kn) break;                                   // wave-uniform
+            const unsigned rcur = rq[d];
+            const unsigned c0 = __builtin_amdgcn_readlane(mybeg, i), c1 = __builtin_amdgcn_readlane(myend, i);
+            if (i + PF < kn) {
+                const unsigned qb = __builtin_amdgcn_readlane(mybeg, i + PF), qe = __builtin_amdgcn_readlane(myend, i + PF);
+                rq[d] = qb + lane < qe ? recs[qb + lane] : 0xffffffffu;
+            }
+            if (c1 > c0) {                                        // wave-uniform
+                dirty = true;
+                // pass 1: every event of the bucket marks (pixel, slice)
+                if (rcur != 0xffffffffu) atomicOr(&ml[rcur & (TILE_PX - 1)], 1ull << (rcur >> TILE_SHIFT));
+                for (unsigned q = c0 + 64 + lane; q < c1; q += 64) {
+                    const unsigned r = recs[q];
+                    atomicOr(&ml[r & (TILE_PX - 1)], 1ull << (r >> TILE_SHIFT));
+                }
+                // pass 2: one lane per touched pixel claims its mask and replays the slices (LDS operations of a wave
+                // execute in order: every mark above is visible here; the fences keep the compiler from moving them)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                auto settle = [&](unsigned r) {
+                    const unsigned pix = r & (TILE_PX - 1);
+                    unsigned long long m = atomicExch(&ml[pix], 0ull);
+                    if (m) {
+                        float ww = wl[pix];
+                        for (; m; m &= m - 1) ww = update_drive(ww, da);
+                        wl[pix] = ww;
+                        bl[pix] = surface_gray_one(ww, neg_lam, mode);
+                    }
+                };
+                if (rcur != 0xffffffffu) settle(rcur);
+                for (unsigned q = c0 + 64 + lane; q < c1; q += 64) settle(recs[q]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (live) {
+                const u4v bytes = reinterpret_cast<const u4v*>(bl)[lane];
+                __builtin_nontemporal_store(bytes, reinterpret_cast<u4v*>(frames + (size_t)(kb + i) * frame_stride + yy * row_stride + xx));
+            }
+          }
+        }
+    }
+    if (dirty && live) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) reinterpret_cast<f4v*>(w + p0)[j] = reinterpret_cast<const f4v*>(wl + lane * 16)[j];
+    }
+}
+
 // bincount_2d (event_mem_sim.py:100-104): events per pixel.
 __global__ __launch_bounds__(256) void k_bincount(const short* __restrict__ x, const short* __restrict__ y, size_t n,
                                                    int W, int* __restrict__ counts)
@@ -709,6 +876,11 @@ struct nsof_accum {
     unsigned* mask[2] = {nullptr, nullptr};
     unsigned* mask_hi = nullptr;   // slices 32..63 of a dense scheme-1 group (allocated on first use, kept zero between groups)
     unsigned long long* mask64 = nullptr;   // nsof_accum_run_frames (copy + patch): one 64-bit slice mask per pixel
+    // nsof_accum_run_frames (tile walk): bucket counters / offsets [intervals * tiles (+1)] and the 16-bit event records
+    unsigned* tile_cnt = nullptr;
+    unsigned* tile_off = nullptr;
+    unsigned short* tile_recs = nullptr;
+    size_t tile_nb_cap = 0, tile_rec_cap = 0;
     unsigned* list[2] = {nullptr, nullptr};
     size_t list_cap = 0;
     unsigned* count = nullptr;  // [2]
@@ -734,6 +906,7 @@ struct nsof_accum {
     bool graph_dense = false, graph_sparse_ok = false;
     int use_graph = -1;   // -1: from the environment (NSOF_ACCUM_GRAPH=1 switches it on), 0 / 1: forced
     int v2_per_slice = -1;   // scheme 2: 0 = one scatter per group + refractory walk in the update (default), 1 = one scatter per slice
+    int frames_path = 0;     // nsof_accum_run_frames: 0 = the tile walk where it applies, 1 = copy + patch per interval (kept as the cross-check)
 };
 
 static int accum_alloc(nsof_ctx* ctx, void** p, size_t bytes)
@@ -754,7 +927,7 @@ extern "C" void nsof_accum_destroy(nsof_accum* a)
     for (int i = 0; i < 2; i++) {
         hipFree(a->w[i]); hipFree(a->next_ok[i]); hipFree(a->mask[i]); hipFree(a->list[i]); hipFree(a->snap[i]);
     }
-    hipFree(a->mask_hi); hipFree(a->mask64); hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
+    hipFree(a->mask_hi); hipFree(a->mask64); hipFree(a->tile_cnt); hipFree(a->tile_off); hipFree(a->tile_recs); hipFree(a->count); hipFree(a->dx); hipFree(a->dy); hipFree(a->dp); hipFree(a->dbounds);
     hipFree(a->d_slices); hipFree(a->d_groups); hipFree(a->d_gi);
     if (a->graph) hipGraphExecDestroy(a->graph);
     delete a;
@@ -802,6 +975,13 @@ extern "C" int nsof_accum_create(nsof_ctx* ctx, int height, int width, int schem
     if (!rc) rc = nsof_accum_reset(a);
     if (rc) { nsof_accum_destroy(a); return rc; }
     *out = a;
+    return NSOF_OK;
+}
+
+extern "C" int nsof_accum_set_frames_path(nsof_accum* a, int path)
+{
+    if (!a || path < 0 || path > 1) return NSOF_EINVAL;
+    a->frames_path = path;
     return NSOF_OK;
 }
 
@@ -1251,6 +1431,44 @@ extern "C" int nsof_accum_run_frames(nsof_accum* a, int64_t first_slice, int64_t
     }
     NSOF_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
+    const std::vector<long long>& relv = a->h_rel;
+    const long long ev0 = relv[first_slice], n_ev = relv[first_slice + n_frames * every] - ev0;
+    // ---- the tile walk: whole run in four launches (frames write-only); needs 16-byte-addressable frame rows
+    const bool tile_ok = (a->W & 15) == 0 && (row_stride & 15) == 0 && (frame_stride & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(d_frames) & 15) == 0 && n_frames >= 2 && n_ev < (1ll << 31) &&
+                         (a->npx + TILE_PX - 1) / TILE_PX <= 15000 &&   // the bucketing workgroup's histogram: 4 B per tile of LDS
+                         (size_t)n_frames * ((a->npx + TILE_PX - 1) / TILE_PX) < ((size_t)1 << 30) && a->frames_path != 1;
+    if (tile_ok) {
+        const unsigned ntiles = (unsigned)((a->npx + TILE_PX - 1) / TILE_PX);
+        const size_t nb = (size_t)n_frames * ntiles;
+        if (nb + 1 > a->tile_nb_cap) {
+            NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(a->tile_cnt); hipFree(a->tile_off);
+            a->tile_cnt = a->tile_off = nullptr;
+            a->tile_nb_cap = 0;
+            const size_t cap = nb + nb / 4 + 1024;
+            if ((rc = accum_alloc(ctx, (void**)&a->tile_off, cap * 4))) return rc;
+            a->tile_nb_cap = cap;
+        }
+        if ((size_t)n_ev > a->tile_rec_cap) {
+            NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(a->tile_recs);
+            a->tile_recs = nullptr;
+            a->tile_rec_cap = 0;
+            const size_t cap = (size_t)n_ev + (size_t)n_ev / 4 + 1024;
+            if ((rc = accum_alloc(ctx, (void**)&a->tile_recs, cap * 2))) return rc;
+            a->tile_rec_cap = cap;
+        }
+        nsof_prof_scope ps(ctx, NSOF_K_ACCUM);
+        hipLaunchKernelGGL(k_tile_bucket, dim3((unsigned)n_frames), dim3(1024), (size_t)ntiles * 4, ctx->stream, a->dx, a->dy, ev0,
+                           a->dbounds + first_slice, (int)every, a->W, ntiles, a->tile_off, a->tile_recs, (int)n_frames);
+        hipLaunchKernelGGL(k_tile_frames, dim3((ntiles + 3) / 4), dim3(256), 0, ctx->stream, a->w[0], a->npx, a->W,
+                           (const unsigned*)a->tile_off, (const unsigned short*)a->tile_recs, ntiles, (int)n_frames, a->active_v, d_frames,
+                           (long long)row_stride, (long long)frame_stride, neg_lam, mode);
+        NSOF_HIP(ctx, hipGetLastError());
+        a->slice_counter += n_frames * every;
+        return NSOF_OK;
+    }
     if (!a->mask64) {   // per-pixel 64-bit slice masks of this path (kept zero between intervals)
         if ((rc = accum_alloc(ctx, (void**)&a->mask64, a->npx * sizeof(unsigned long long)))) return rc;
         NSOF_HIP(ctx, hipMemsetAsync(a->mask64, 0, a->npx * sizeof(unsigned long long), ctx->stream));

@@ -77,6 +77,7 @@ SIGNATURES = {
     "nsof_accum_surface_u8_dev": (_i, [_vp, _i, _i, _vp, _pd]),
     "nsof_accum_run_surface": (_i, [_vp, _i64, _i64, _i, _i, _vp, _pd]),
     "nsof_accum_run_frames": (_i, [_vp, _i64, _i64, _i64, _i, _i, _vp, _pd, _pd]),
+    "nsof_accum_set_frames_path": (_i, [_vp, _i]),
     "nsof_accum_read_state": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i64)]),
     "nsof_accum_write_state": (_i, [_vp, _i, _vp, _vp, _i64]),
     "nsof_accum_update_state_dev": (_i, [_vp, _vp, _vp, _vp, _sz]),

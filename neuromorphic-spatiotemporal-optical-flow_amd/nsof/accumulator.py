@@ -136,7 +136,7 @@ class Accumulator:
     """Device-resident array state (w, refractory maps) that can be advanced chunk by chunk."""
 
     def __init__(self, height, width, version=1, polarity="split", active_v=-8.0, silent_v=0.0, *, ctx=None,
-                 dense=None):
+                 dense=None, frames_path=None):
         if version not in (1, 2):
             raise NsofValueError("version must be 1 or 2")
         if polarity not in ("split", "magnitude"):
@@ -150,6 +150,9 @@ class Accumulator:
         self._p = p
         if dense is not None:   # None: automatic; True: the every-pixel pass; False: the event-pixel update where it is exact
             self.ctx.check(self.ctx._lib.nsof_accum_set_dense(self._p, 1 if dense else -1), "accum_set_dense")
+        if frames_path is not None:   # run_frames: "tiles" (default where it applies) or "copy_patch"
+            self.ctx.check(self.ctx._lib.nsof_accum_set_frames_path(self._p, {"tiles": 0, "copy_patch": 1}[frames_path]),
+                           "accum_set_frames_path")
 
     def reset(self):
         self.ctx.check(self.ctx._lib.nsof_accum_reset(self._p), "accum_reset")

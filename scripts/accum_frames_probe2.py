@@ -22,8 +22,8 @@ ctx = nsof.Context(0)
 dev = torch.device("cuda", 0)
 out = {"frames": n_fr, "slices": n_fr * every}
 ref = None
-for name, dense in (("every_pixel_pass", True), ("copy_patch", None)):
-    acc = Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=ctx, dense=dense)
+for name, dense, fpath in (("every_pixel_pass", True, None), ("copy_patch", None, "copy_patch"), ("tile_walk", None, None)):
+    acc = Accumulator(H, W, 1, "split", -6.0, 0.0, ctx=ctx, dense=dense, frames_path=fpath)
     acc.set_events(x, y, p, t, idx)
     frames = torch.empty((n_fr, H, W), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
@@ -40,8 +40,8 @@ for name, dense in (("every_pixel_pass", True), ("copy_patch", None)):
     if ref is None:
         ref = (frames.clone(), acc.w())
     else:
-        out["frames_identical"] = bool(torch.equal(frames, ref[0]))
-        out["state_identical"] = bool((acc.w() == ref[1]).all())
+        out[name]["frames_identical_to_every_pixel_pass"] = bool(torch.equal(frames, ref[0]))
+        out[name]["state_identical"] = bool((acc.w() == ref[1]).all())
     out[name]["checksum"] = chk
     acc.close()
 print(json.dumps(out))

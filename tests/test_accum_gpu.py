@@ -570,24 +570,28 @@ def test_run_surface_equals_run_then_surface(nsof_lib, ctx):
 
 @pytest.mark.gpu
 def test_run_frames_copy_patch_equals_dense_frames(nsof_lib, ctx, oracle):
-    """nsof_accum_run_frames: with the silent voltage in the dead zone a frame is its predecessor copied and patched at the
-    event pixels (two small launches per interval) -- frames and final state byte-identical to the every-pixel pass per
-    interval (dense=True takes n x run_surface), both surface modes, intervals of 33 / 7 / 64 slices, dense and strided frame
-    tensors, a second call that continues the stream; the state against the CPU oracle; a silent voltage OUTSIDE the dead
-    zone takes the generic path through the same entry."""
+    """nsof_accum_run_frames: with the silent voltage in the dead zone the frames come from an event-driven form -- the tile
+    walk (a wave owns 1024 pixels for the whole run, frames write-only: two launches per call) or, where the shape does
+    not allow it / on request, copy + patch per interval -- frames and final state byte-identical to the every-pixel pass
+    per interval (dense=True takes n x run_surface), both surface modes, intervals of 33 / 7 / 64 / 20 slices, dense and
+    strided frame tensors, widths that are / are not multiples of 16, tiles that end inside the image, a second call that
+    continues the stream; the state against the CPU oracle; a silent voltage OUTSIDE the dead zone takes the generic path
+    through the same entry."""
     import torch
     from nsof import synth
     from nsof.accumulator import Accumulator, slice_index_array
     dev = torch.device("cuda", ctx.device)
-    for (H, W, every, pad, silent) in [(120, 160, 33, 0, 0.0), (77, 131, 7, 5, 0.0), (96, 128, 64, 0, 0.05), (90, 202, 33, 0, 0.5)]:
+    for (H, W, every, pad, silent) in [(120, 160, 33, 0, 0.0), (77, 131, 7, 5, 0.0), (96, 128, 64, 0, 0.05), (90, 202, 33, 0, 0.5),
+                                       (50, 208, 33, 16, 0.0), (129, 1040, 20, 0, 0.0)]:
         x, y, p, t = synth.make_events(9, W, H, 9000, 200_000, box=(20, 16))
         idx = slice_index_array(t, 1000)
         n_fr = (len(idx) - 1) // every
         assert n_fr >= 3
         for mode in ("state", "current"):
             got = {}
-            for dense in (True, None):
-                acc = Accumulator(H, W, 1, "split", -6.0, silent, ctx=ctx, dense=dense)
+            # the every-pixel pass per interval; copy + patch per interval; the tile walk (default where the shape allows)
+            for dense, fpath in ((True, None), ("cp", "copy_patch"), (None, None)):
+                acc = Accumulator(H, W, 1, "split", -6.0, silent, ctx=ctx, dense=True if dense is True else None, frames_path=fpath)
                 try:
                     acc.set_events(x, y, p, t, idx)
                     buf = torch.zeros((n_fr, H, W + pad), dtype=torch.uint8, device=dev)
@@ -600,6 +604,7 @@ def test_run_frames_copy_patch_equals_dense_frames(nsof_lib, ctx, oracle):
                     acc.close()
             assert np.array_equal(got[None][0], got[True][0]), (H, W, every, silent, mode)
             assert np.array_equal(got[None][1], got[True][1])
+            assert np.array_equal(got["cp"][0], got[True][0]) and np.array_equal(got["cp"][1], got[True][1]), (H, W, every, silent, mode)
             assert got[None][0][:, :, :W].any() and not got[None][0][:, :, W:].any()
             if mode == "state":   # (the current -> gray map saturates at 255 for w >= 0.42: those frames are constant)
                 assert len({got[None][0][k].tobytes() for k in range(n_fr)}) > 1          # the frames do change
