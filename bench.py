@@ -544,8 +544,11 @@ def config3_leg(nsof, torch, local_rank):
     from oracle import oracle as O  # noqa: N812
     H, W, every, ms = 720, 1280, 33, 20  # noqa: N806
     pa = [getattr(PARAMS_A, kk) for kk in ("pyr_scale", "levels", "winsize", "iterations", "poly_n", "poly_sigma", "flags")]
+    # bug_compatible=False: pair (k, k+1) is gated by the map of frame k+1, as opticalFlow3D is written and as rounds 2-3
+    # measured this leg (the library's default follows the shipped scripts, memimg2 := memimg1 -> frame k; both are tested:
+    # tests/test_gating.py::test_config3_roi_flow_pipeline_vs_oracle_chain)
     cfg = gating.GatingConfig(MEMSIZE=ms, EXTEND_HEIGHT_UPPER=20, EXTEND_HEIGHT_LOWER=20, EXTEND_WIDTH_LEFT=20,
-                              EXTEND_WIDTH_RIGHT=20, THRES=240, FLAG=1, farneback_params=PARAMS_A)
+                              EXTEND_WIDTH_RIGHT=20, THRES=240, FLAG=1, farneback_params=PARAMS_A, bug_compatible=False)
     _, _, _, usable = O.host_cpu()
     nt = min(usable, 16)
     rec = {"workload": f"events -> scheme-1 surface -> 8-bit frames + gating maps every {every} slices -> device ROI -> "
@@ -985,10 +988,11 @@ def e2e_leg(nsof, p, prevs, nexts, flow, k, local_rank):
         t0 = time.perf_counter()
         nsof.farneback_pairs(pairs[:kk], p, pageable, ctx=c2)
         out["e2e"]["pageable_outputs_pairs_per_s"] = round(kk / (time.perf_counter() - t0), 1)
+        nsof.calcOpticalFlowFarneback(hp[0], hn[0], None, **p.as_kwargs(), ctx=c2)   # warm-up: workspace, side stream, staging
         t0 = time.perf_counter()                           # one synchronous call per pair, the reference's pattern
-        for i in range(min(k, 16)):
+        for i in range(min(k, 32)):
             nsof.calcOpticalFlowFarneback(hp[i], hn[i], None, **p.as_kwargs(), ctx=c2)
-        out["e2e"]["one_call_per_pair_pairs_per_s"] = round(min(k, 16) / (time.perf_counter() - t0), 1)
+        out["e2e"]["one_call_per_pair_pairs_per_s"] = round(min(k, 32) / (time.perf_counter() - t0), 1)
     return out
 
 

@@ -150,3 +150,31 @@ def test_flowviz_matches_reference_goldens(nsof_lib):
             assert np.array_equal(flowviz.flow_to_image(flow), z[f"{name}_rgb"]), name
             assert np.array_equal(flowviz.flow_to_image(flow, convert_to_bgr=True), z[f"{name}_bgr"]), name
             assert np.array_equal(flowviz.flow_to_image(flow, clip_flow=2.5), z[f"{name}_clip"]), name
+
+
+def test_global_slice_times_and_band_bounds(nsof_lib):
+    """nsof.dist helpers of the row-band sharding (host arithmetic): the first / last event time of every slice of the whole
+    stream (what scheme 2's refractory rule reads, /root/reference/eventsim/event_mem_sim.py:243-267), a band's events on
+    the GLOBAL slice grid, and the bands themselves."""
+    import numpy as np
+    from nsof import dist as nd
+    from nsof.accumulator import slice_index_array
+    t = np.array([5, 7, 1003, 1004, 1999, 4100, 4100, 4990], np.int64)       # slices of 1000 us from t[0] = 5
+    y = np.array([0, 9, 3, 8, 1, 9, 2, 7], np.int64)
+    x = np.arange(8)
+    p = np.ones(8, np.int64)
+    idx = slice_index_array(t, 1000)
+    tf, tl = nd.global_slice_times(t, 1000)
+    assert len(tf) == len(idx) - 1 == 5
+    assert tf.tolist() == [5, 1999, 0, 0, 4100] and tl.tolist() == [1004, 1999, 0, 0, 4990]   # [5,1005) holds 5, 7, 1003, 1004
+    for s in range(len(idx) - 1):                                             # == the reference's t_us[sl.start] / t_us[sl.stop - 1]
+        if idx[s + 1] > idx[s]:
+            assert tf[s] == t[idx[s]] and tl[s] == t[idx[s + 1] - 1]
+    assert nd.band_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    xb, yb, pb, tb, sel = nd.events_in_band(x, y, p, t, 4, 10)
+    assert sel.tolist() == [1, 3, 5, 7] and yb.tolist() == [5, 4, 5, 3]
+    ib = nd.band_slice_bounds(t, tb, 1000)
+    assert len(ib) == len(idx) and ib.tolist() == [0, 2, 2, 2, 2, 4][:len(idx)]
+    # a band's own first event of slice 0 (7) differs from the stream's (5): the table exists for this reason
+    assert tb[ib[0]] == 7 != tf[0]
+
