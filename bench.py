@@ -13,7 +13,7 @@ for the barrier and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
   roofline     -- dominant kernel by summed device time, timed live with HIP events on the launch
-                  stream inside the timed region; algorithmic bytes per DESIGN.md section "roofline"
+                  stream inside the timed region; algorithmic bytes per DESIGN.md section 5
   roofline_polyexp -- the same for the polynomial-expansion kernel (the north-star kernel)
   cpu_baseline -- the CPU oracle (oracle/farneback_ref.c, 1 thread) on a bounded sample of the same pairs
   max_abs_epe_vs_oracle -- GPU flow vs oracle flow on that sample
@@ -81,7 +81,7 @@ def level_sizes(nsof, w, h, p):
 
 
 def algorithmic_bytes_per_pair(nsof, w, h, p):
-    """Per-kernel compulsory HBM bytes for ONE frame pair (DESIGN.md 'roofline')."""
+    """Per-kernel compulsory HBM bytes for ONE frame pair."""
     from nsof import _lib
     sizes = level_sizes(nsof, w, h, p)
     n0 = w * h

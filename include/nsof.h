@@ -74,7 +74,7 @@ int nsof_synchronize(nsof_ctx* ctx);
  * (automatic height; applied from winsize 9 up), >= 4 = bands of that many rows at any window: each band starts its
  * column sums with a direct sum of its first window, which lacks the rounding history of the running sum -- the same
  * class of deviation as the row-sum order above but more frequent: ~1e-5 on textured frames with wide windows, 4th
- * decimal at many pixels with 3x3 / 4x4 windows (DESIGN.md section 5.1 has the soak counts).  Off by default so that a
+ * decimal at many pixels with 3x3 / 4x4 windows (docs/HISTORY_r1_r3.md section 5.1 has the soak counts).  Off by default so that a
  * pair's flow does not depend on the batch it was part of.  Values 2 and 3 are rejected.  Environment default:
  * NSOF_ROW_BANDS. */
 /* NSOF_OPT_PYR_FMA (default 0): the arithmetic-variant twin of the pyramid stages.  0 = the float Gaussian blur and the

@@ -175,7 +175,7 @@ struct PCGeom {
     // themselves, the even columns A[j] = v[2j], the pair sums P[j] = v[2j] + v[2j+1] and the quad sums
     // Q[j] = P[2j] + P[2j+1] (+ one 0.0) -- a (2m+1)-window sum then takes about m/2 + 5 LDS reads instead of
     // 2m + 3.  The row sums are bound by LDS bandwidth (every column sum used to be read 2m+1 times by 4 waves at
-    // once, right after the barrier), see DESIGN.md 5.1.
+    // once, right after the barrier), see docs/HISTORY_r1_r3.md section 5.1.
 #ifdef NSOF_NO_HIER   // A/B build: the plain layout (every column sum read 2m+1 times)
     static constexpr bool HIER = false;
 #else
@@ -1061,7 +1061,7 @@ int launch_iterate_q(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R
     // walks the whole height; bands of rows add workgroups at the price of 2m+1 extra rows per band.  1 = automatic
     // (bands no shorter than 32 rows, until the launch has about two workgroups per CU), >= 4 = that many rows.
     // Automatic mode only from winsize 9 up: with small windows the 2x2 systems are rank deficient often enough that a
-    // band's restart shows in the 4th decimal of many pixels (parity soak); an explicit row
+    // band's restart shows in the 4th decimal of many pixels (parity soak, docs/HISTORY_r1_r3.md section 5.1); an explicit row
     // count is taken at its word.
     int band_rows = 0;
     if (ctx->opt_row_bands > 0) {
@@ -1257,7 +1257,7 @@ int nsof_launch_iterate(nsof_ctx* ctx, int n_pairs, const float* R0, const float
 }
 
 // First iteration of a level, reading the previous (coarser) level's flow and resampling it on the fly (tuning builds
-// only: NSOF_FOLD_UPSAMPLE measured slower than the standalone resample kernel).
+// only: NSOF_FOLD_UPSAMPLE measured slower than the standalone resample kernel, docs/HISTORY_r1_r3.md section 5).
 bool nsof_iterate_upsample_supported(int winsize, int W, int H)
 {
 #ifdef NSOF_AB
