@@ -69,6 +69,86 @@ int fallback_item(nsof_ctx* ctx, const nsof_pair_desc& d, const Params& p)
     return NSOF_OK;
 }
 
+// A size class of a level's item table: items [start, start + count) with extents up to max_w x max_h.
+struct HetClass {
+    int start, count, max_w, max_h;
+};
+
+// Sorts a level's items into size classes (power-of-two buckets of width and height).  The tiled kernels of a level
+// launch a grid over the LARGEST extents of the items they are given and workgroups outside an item leave at once; with
+// one full frame among thousands of small crops nearly every workgroup of such a launch would be one of those (measured:
+// 1.9 of 2.0 ms of a level-0 launch), so each class gets its own launch.  Classes with few items share one catch-all.
+void sort_into_classes(nsof_het_item* t, int n, std::vector<std::pair<int, int>>& keyed, std::vector<nsof_het_item>& sorted,
+                       std::vector<HetClass>& out)
+{
+    out.clear();
+    if (n == 0) return;
+    auto bucket = [](int v, int first) {
+        int b = 0;
+        while (b < 7 && v > (first << b)) b++;
+        return b;
+    };
+    int count[64] = {0};
+    keyed.resize(n);
+    for (int i = 0; i < n; i++) {
+        const int key = bucket(t[i].hk, 16) * 8 + bucket(t[i].wk, 64);
+        keyed[i] = {key, i};
+        count[key]++;
+    }
+    // own launch: the 6 most populated buckets with at least 16 items; the rest -> catch-all (key 64)
+    int order[64];
+    for (int i = 0; i < 64; i++) order[i] = i;
+    std::stable_sort(order, order + 64, [&](int a, int b) { return count[a] > count[b]; });
+    bool own[64] = {false};
+    for (int r = 0; r < 6; r++) own[order[r]] = count[order[r]] >= 16;
+    for (auto& kv : keyed)
+        if (!own[kv.first]) kv.first = 64;
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    sorted.resize(n);
+    for (int i = 0; i < n; i++) sorted[i] = t[keyed[i].second];
+    memcpy(t, sorted.data(), (size_t)n * sizeof(nsof_het_item));
+    for (int i = 0; i < n; i++) {
+        if (i == 0 || keyed[i].first != keyed[i - 1].first) out.push_back({i, 0, 0, 0});
+        HetClass& c = out.back();
+        c.count++;
+        c.max_w = std::max(c.max_w, t[i].wk);
+        c.max_h = std::max(c.max_h, t[i].hk);
+    }
+}
+
+// The fused iteration kernel's job table of one level (layout: k_iterate_x; *stride = the longest list).  Items go to the
+// XCD list with the least work so far, tallest first, the strips of an item one after the other (a strip waits for its
+// left neighbour's carries, which must therefore have been taken earlier from the same list).  Returns the number of
+// jobs; the table takes 8 + 8 * *stride words.
+int build_xjobs(const nsof_het_item* t, int n, unsigned* xj, int* stride, std::vector<std::pair<int, int>>& order,
+                std::vector<unsigned> (&lists)[8])
+{
+    order.resize(n);
+    for (int i = 0; i < n; i++) order[i] = {t[i].hk, i};
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    long long load[8] = {0};
+    for (auto& l : lists) l.clear();
+    int jobs = 0;
+    for (int r = 0; r < n; r++) {
+        const int i = order[r].second;
+        const int strips = (t[i].wk + NSOF_X_STRIP - 1) / NSOF_X_STRIP;
+        int x = 0;
+        for (int k = 1; k < 8; k++)
+            if (load[k] < load[x]) x = k;
+        for (int s = 0; s < strips; s++) lists[x].push_back((unsigned)i << 8 | (unsigned)s);
+        load[x] += (long long)strips * ((t[i].hk + 3) / 4 + 12);   // steps of the walk + a job's start-up
+        jobs += strips;
+    }
+    size_t longest = 1;
+    for (auto& l : lists) longest = std::max(longest, l.size());
+    for (int k = 0; k < 8; k++) {
+        xj[k] = (unsigned)lists[k].size();
+        if (!lists[k].empty()) memcpy(xj + 8 + (size_t)k * longest, lists[k].data(), lists[k].size() * sizeof(unsigned));
+    }
+    *stride = (int)longest;
+    return jobs;
+}
+
 // The work-list driver.  descs: HOST array whose pointers are DEVICE addresses.
 int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
 {
@@ -114,8 +194,19 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
             Li[j] = nsof_farneback_effective_levels(descs[het[j]].width, descs[het[j]].height, p.pyr_scale, p.levels);
             Lmax = std::max(Lmax, Li[j]);
         }
+        // Per level: the item table (sorted into size classes), then the fused kernel's job table (8 counts + 8 lists).
+        long long strips0 = 0;   // strips of the full-resolution level = the most any level has
+        for (int j = 0; j < nh; j++) {
+            const int st = (descs[het[j]].width + NSOF_X_STRIP - 1) / NSOF_X_STRIP;
+            if (st > 255) return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "item %d: width %d above %d", het[j], descs[het[j]].width, 255 * NSOF_X_STRIP);
+            strips0 += st;
+        }
+        if (strips0 >= (1ll << 26) || nh >= (1 << 24))
+            return nsof_set_error(ctx, NSOF_EINVAL, "work list too long (%d items, %lld strips)", nh, strips0);
+        const size_t xj_words = align_up(8 + 8 * (size_t)strips0, 64);   // words per level at most (every strip in one list)
+        const size_t items_bytes = align_up((size_t)(Lmax + 1) * nh * sizeof(nsof_het_item), 256);
         // two table slots used alternately: the upload of call c may still be queued when call c+1 builds its tables
-        const size_t tab_bytes = align_up((size_t)(Lmax + 1) * nh * sizeof(nsof_het_item), 256);
+        const size_t tab_bytes = align_up(items_bytes + (size_t)(Lmax + 1) * xj_words * sizeof(unsigned), 256);
         if (ctx->het_bytes < 2 * tab_bytes) {
             NSOF_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->het_h) hipHostFree(ctx->het_h);
@@ -134,12 +225,20 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
         const size_t slot_off = (size_t)slot * (ctx->het_bytes / 2);
         nsof_het_item* tabs = (nsof_het_item*)((char*)ctx->het_h + slot_off);
         const nsof_het_item* d_tabs = (const nsof_het_item*)((char*)ctx->het_d + slot_off);
+        unsigned* xj = (unsigned*)((char*)ctx->het_h + slot_off + items_bytes);
+        const unsigned* d_xj = (const unsigned*)((char*)ctx->het_d + slot_off + items_bytes);
 
         // Build the tables, coarsest level first in memory order k = 0..Lmax (table k at tabs + k*nh).
-        std::vector<int> cnt(Lmax + 1, 0);
+        std::vector<int> cnt(Lmax + 1, 0), xj_jobs(Lmax + 1, 0), xj_stride(Lmax + 1, 1);
+        std::vector<size_t> xj_at(Lmax + 1, 0);   // word offset of level k's job table
+        std::vector<unsigned> lists[8];
+        size_t xj_used = 0;
         std::vector<unsigned long long> offF_prev(nh, 0);   // the item's flow offset at the next coarser level
         size_t maxI = 0, maxR = 0, maxF = 0;
         std::vector<int> max_w(Lmax + 1, 0), max_h(Lmax + 1, 0);
+        std::vector<std::vector<HetClass>> classes(Lmax + 1);
+        std::vector<std::pair<int, int>> keyed;   // (class key, position) scratch
+        std::vector<nsof_het_item> sorted;
         for (int k = Lmax; k >= 0; k--) {
             unsigned long long oI = 0, oR = 0, oF = 0;
             nsof_het_item* t = tabs + (size_t)k * nh;
@@ -167,8 +266,12 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
                 t[cnt[k]++] = it;
             }
             maxI = std::max(maxI, (size_t)oI); maxR = std::max(maxR, (size_t)oR); maxF = std::max(maxF, (size_t)oF);
+            sort_into_classes(t, cnt[k], keyed, sorted, classes[k]);
+            xj_at[k] = xj_used;
+            xj_jobs[k] = build_xjobs(t, cnt[k], xj + xj_used, &xj_stride[k], keyed, lists);
+            xj_used += align_up(8 + 8 * (size_t)xj_stride[k], 64);
         }
-        NSOF_HIP(ctx, hipMemcpyAsync((void*)d_tabs, tabs, tab_bytes, hipMemcpyHostToDevice, ctx->stream));
+        NSOF_HIP(ctx, hipMemcpyAsync((void*)d_tabs, tabs, items_bytes + xj_used * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
         NSOF_HIP(ctx, hipEventRecord(ctx->het_ev[slot], ctx->stream));
 
         // workspace: level images, expansions, two flow buffers (every level uses their leading part)
@@ -202,13 +305,16 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
             const nsof_het_item* dt = d_tabs + (size_t)k * nh;
             const nsof_het_item* ht = tabs + (size_t)k * nh;
             const int nk_items = cnt[k];
-            // incoming flow of the level: resample of the coarser level's field (zero for items that start here)
-            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample_het, nk_items, dt, max_w[k], max_h[k], fb[cur], fb[cur ^ 1],
-                                                    (float)(1. / p.pyr_scale))))
-                return rc;
+            // incoming flow of the level (resample of the coarser level's field, zero for items that start here), level
+            // image and expansion: grids over the largest extents of a size class, one launch per class
+            for (const HetClass& c : classes[k]) {
+                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample_het, c.count, dt + c.start, c.max_w, c.max_h, fb[cur],
+                                       fb[cur ^ 1], (float)(1. / p.pyr_scale))))
+                    return rc;
+                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_het, c.count, dt + c.start, ht + c.start, k == 0, btaps, dI))) return rc;
+                if ((rc = nsof_launch_polyexp_het(ctx, c.count, dt + c.start, c.max_w, c.max_h, ptaps, dI, dR))) return rc;
+            }
             cur ^= 1;
-            if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_het, nk_items, dt, ht, k == 0, btaps, dI))) return rc;
-            if ((rc = nsof_launch_polyexp_het(ctx, nk_items, dt, max_w[k], max_h[k], ptaps, dI, dR))) return rc;
             for (int it = 0; it < p.iterations; it++) {
                 const bool final = k == 0 && it == p.iterations - 1;
                 if (exact_lat)
@@ -216,7 +322,7 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
                                                      dM, dV);
                 else if (exact_x)
                     rc = nsof_launch_iterate_x_het(ctx, nk_items, dt, max_w[k], max_h[k], dR, szR / 4, fb[cur], fb[cur ^ 1], final,
-                                                   p.winsize);
+                                                   p.winsize, d_xj + xj_at[k], xj_stride[k], xj_jobs[k]);
                 else if (exact)
                     rc = nsof_launch_iterate_het_exact(ctx, nk_items, dt, max_w[k], max_h[k], dR, fb[cur], fb[cur ^ 1], final,
                                                        p.winsize, dV);

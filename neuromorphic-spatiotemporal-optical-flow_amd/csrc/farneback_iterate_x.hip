@@ -749,12 +749,16 @@ __device__ __forceinline__ void x_scanner_loop(double* sv, const double* vinit, 
 }
 
 // tickets: 8 counters, 32 words apart.  carry: granules, see the launcher.  n: pairs (items with HET); nstrips: strips of
-// the widest image of the launch.
+// the image.  Work lists (HET) carry a job table instead: xjobs[0..7] = jobs in each XCD's list, xjobs[8 + k * nstrips + i]
+// = item << 8 | strip, the i-th job of XCD k's list (nstrips = the lists' common stride); built on the host so that
+// only strips that exist are ever taken and the strips of an item follow each other in one list.  The grid is exactly
+// the number of jobs: a workgroup whose XCD's list has run out takes the next job of another list.
 template <int MH, bool HET>
 __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
     const float* __restrict__ R0b, const float* __restrict__ R1b, size_t pair_stride, const float* __restrict__ flow_in,
     float* __restrict__ flow_out, int W, int H, int block_size, const nsof_het_item* __restrict__ items, int het_final,
-    int n, int nstrips, unsigned long long* carry, unsigned* tickets, unsigned epoch, unsigned* err, int fault)
+    int n, int nstrips, unsigned long long* carry, unsigned* tickets, unsigned epoch, unsigned* err, int fault,
+    const unsigned* __restrict__ xjobs)
 {
     using G = XGeom<MH>;
     constexpr int SW = G::SW, COLS = G::COLS;
@@ -770,20 +774,29 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
     const int tid = threadIdx.x;
     // ---- job: (pair, strip) from this XCD's ticket counter, strips of a pair in order
     if (tid == 0) {
-        const unsigned share = (unsigned)((n + 7) / 8) * (unsigned)nstrips;
+        // the jobs of XCD k: pairs k, k + 8, ... strip by strip; work lists: xjobs[k] entries of list k
+        const unsigned share = HET ? 0u : (unsigned)((n + 7) / 8) * (unsigned)nstrips;
         unsigned k = xcc_id();
+        unsigned lim = HET ? xjobs[k] : share;
         unsigned i = __hip_atomic_fetch_add(tickets + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // a hand-over already timed out on this context (this launch or an earlier one of the same call): the call will
         // fail whatever this workgroup computes, so it leaves at once -- a failed call drains in one time-out
-        if (__hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) i = 0xffffffffu, k = 0;
-        if (i >= share) {   // more workgroups landed on this XCD than its share: take another XCD's next job
-            for (unsigned d = 1; d < 8 && i >= share; d++) {
+        if (__hip_atomic_load((gu32*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) i = 0xffffffffu, lim = 0;
+        else if (i >= lim) {   // more workgroups landed on this XCD than its share: take another XCD's next job
+            for (unsigned d = 1; d < 8 && i >= lim; d++) {
                 k = (k + 1) & 7u;
+                if constexpr (HET) lim = xjobs[k];
                 i = __hip_atomic_fetch_add(tickets + 32 * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        job[0] = i < share ? (int)((i / (unsigned)nstrips) * 8u + k) : -1;
-        job[1] = (int)(i % (unsigned)nstrips);
+        if constexpr (HET) {
+            const unsigned e = i < lim ? xjobs[8u + k * (unsigned)nstrips + i] : 0xffffffffu;
+            job[0] = e != 0xffffffffu ? (int)(e >> 8) : -1;
+            job[1] = (int)(e & 255u);
+        } else {
+            job[0] = i < share ? (int)((i / (unsigned)nstrips) * 8u + k) : -1;
+            job[1] = (int)(i % (unsigned)nstrips);
+        }
         job[2] = job[3] = 0;   // "slots released up to window" flags of the solver wave and of the I/O wave
     }
     __syncthreads();
@@ -901,11 +914,13 @@ __global__ __launch_bounds__((XGeom<MH>::THREADS)) void k_iterate_x(
 
 template <int MH, bool HET>
 int launch_x(nsof_ctx* ctx, int n, int max_w, int max_h, const float* R0, const float* R1, size_t pair_stride,
-             const float* flow_in, float* flow_out, int W, int H, int winsize, const nsof_het_item* items, bool final)
+             const float* flow_in, float* flow_out, int W, int H, int winsize, const nsof_het_item* items, bool final,
+             const unsigned* xjobs, int stride, int njobs)
 {
     using G = XGeom<MH>;
+    static_assert(G::SW == NSOF_X_STRIP, "the host's job tables count strips of NSOF_X_STRIP columns");
     if (int rc = lds_opt_in(ctx, k_iterate_x<MH, HET>, G::SMEM)) return rc;
-    const int nstrips = (max_w + G::SW - 1) / G::SW;
+    const int nstrips = HET ? stride : (max_w + G::SW - 1) / G::SW;
     unsigned long long* carry = nullptr;
     unsigned* tickets = nullptr;
     unsigned* err = nullptr;
@@ -918,9 +933,10 @@ int launch_x(nsof_ctx* ctx, int n, int max_w, int max_h, const float* R0, const 
         NSOF_HIP(ctx, hipMemsetAsync(ctx->x_carry, 0, ctx->x_carry_bytes, ctx->stream));
         epoch = ++ctx->x_epoch;
     }
-    const unsigned grid = 8u * (unsigned)((n + 7) / 8) * (unsigned)nstrips;
+    const unsigned grid = HET ? (unsigned)njobs : 8u * (unsigned)((n + 7) / 8) * (unsigned)nstrips;
     hipLaunchKernelGGL((k_iterate_x<MH, HET>), dim3(grid), dim3(G::THREADS), G::SMEM, ctx->stream, R0, R1, pair_stride, flow_in,
-                       flow_out, W, H, winsize, items, final ? 1 : 0, n, nstrips, carry, tickets, epoch, err, ctx->dbg_fault);
+                       flow_out, W, H, winsize, items, final ? 1 : 0, n, nstrips, carry, tickets, epoch, err, ctx->dbg_fault,
+                       xjobs);
     return NSOF_OK;
 }
 
@@ -950,22 +966,26 @@ int nsof_launch_iterate_x(nsof_ctx* ctx, int n_pairs, const float* R0, const flo
 {
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     int rc;
-    NSOF_X_SWITCH(false, ctx, n_pairs, W, H, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, nullptr, false)
+    NSOF_X_SWITCH(false, ctx, n_pairs, W, H, R0, R1, pair_stride, flow_in, flow_out, W, H, winsize, nullptr, false, nullptr, 0, 0)
     if (rc) return rc;
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;
 }
 
 // Work-list twin; carries go to ctx's mirror of the level's expansion buffer (R_floats = its size in floats).
+// d_xjobs: the job table (see the kernel): 8 counts, then 8 lists `stride` entries apart; njobs = the sum of the counts.
 int nsof_launch_iterate_x_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
-                              size_t R_floats, const float* flow_in, float* flow_out, bool final, int winsize)
+                              size_t R_floats, const float* flow_in, float* flow_out, bool final, int winsize,
+                              const unsigned* d_xjobs, int stride, int njobs)
 {
+    if (njobs <= 0) return NSOF_OK;
     nsof_prof_scope ps(ctx, NSOF_K_ITERATE);
     unsigned long long* carry;
     unsigned *tk, *er;
     if (int rc0 = nsof_xsync_reserve(ctx, R_floats * 4, &carry, &tk, &er)) return rc0;
     int rc;
-    NSOF_X_SWITCH(true, ctx, n_items, max_w, max_h, R, R, (size_t)0, flow_in, flow_out, 0, 0, winsize, d_items, final)
+    NSOF_X_SWITCH(true, ctx, n_items, max_w, max_h, R, R, (size_t)0, flow_in, flow_out, 0, 0, winsize, d_items, final, d_xjobs,
+                  stride, njobs)
     if (rc) return rc;
     NSOF_HIP(ctx, hipGetLastError());
     return NSOF_OK;

@@ -216,8 +216,12 @@ int nsof_launch_iterate_exact(nsof_ctx* ctx, int n_pairs, const float* R0, const
 bool nsof_iterate_x_supported(int winsize, int W, int H);
 int nsof_launch_iterate_x(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                           const float* flow_in, float* flow_out, int W, int H, int winsize);
+// d_xjobs: the level's job table -- 8 counts, then 8 lists (one per XCD, `stride` entries apart) of item << 8 | strip;
+// njobs = the sum of the counts = the grid; strips are NSOF_X_STRIP output columns wide.
+#define NSOF_X_STRIP 192
 int nsof_launch_iterate_x_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h, const float* R,
-                              size_t R_floats, const float* flow_in, float* flow_out, bool final, int winsize);
+                              size_t R_floats, const float* flow_in, float* flow_out, bool final, int winsize,
+                              const unsigned* d_xjobs, int stride, int njobs);
 // Carry buffer of at least `carry_bytes` (0: whatever exists) + ticket / timeout words of that kernel.
 int nsof_xsync_reserve(nsof_ctx* ctx, size_t carry_bytes, unsigned long long** carry, unsigned** tickets, unsigned** err);
 // Reads the timeout word of the exact-order kernel after the stream has drained; NSOF_EDEVICE if a carry never arrived.

@@ -180,6 +180,36 @@ def test_work_list_equals_per_call(nsof_lib, ctx, params):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("small_batch_jobs", [None, 1 << 20])
+def test_skewed_work_list_equals_per_call(nsof_lib, ctx, small_batch_jobs):
+    """One full frame among hundreds of small crops (what gating produces on a sparse stream): the level tables are
+    sorted into size classes with a launch each and the fused kernel takes its (item, strip) jobs from per-XCD lists
+    of the strips that exist -- every flow must still equal the lone call's.  small_batch_jobs=2^20: the same list
+    through the three-kernel small-batch form (whole-level grids over the sorted tables)."""
+    nsof = nsof_lib
+    from nsof import _lib
+    p = nsof.FarnebackParams(*A)
+    rng = np.random.default_rng(77)
+    shapes = [(720, 1280), (300, 400), (17, 500), (410, 33), (500, 17)]
+    shapes += [(int(rng.integers(40, 90)), int(rng.integers(40, 90))) for _ in range(260)]
+    shapes += [(int(rng.integers(100, 260)), int(rng.integers(100, 400))) for _ in range(24)]
+    order = rng.permutation(len(shapes))
+    shapes = [shapes[i] for i in order]
+    pairs = _crops(13, shapes, frame_hw=(720, 1280))
+    if small_batch_jobs is not None:
+        old = ctx.get_option(_lib.OPT_SMALL_BATCH_JOBS)
+        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, small_batch_jobs)
+    try:
+        got = nsof.farneback_pairs(pairs, p, ctx=ctx)
+    finally:
+        if small_batch_jobs is not None:
+            ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, old)
+    for (a, b), g in zip(pairs, got):
+        want = nsof.calcOpticalFlowFarneback(a, b, None, **p.as_kwargs(), ctx=ctx)
+        assert np.array_equal(g, want), (a.shape, float(np.abs(g - want).max()))
+
+
+@pytest.mark.gpu
 def test_work_list_vs_oracle_and_canvas_paste(nsof_lib, ctx, oracle):
     """ROI flows written in place into frame-sized canvases (the paste of optical_flow_seg.py:162/204), pinned and
     pageable targets, several pipeline chunks; compared with the CPU oracle."""
