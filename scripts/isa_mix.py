@@ -47,7 +47,7 @@ def main():
                 if tgt in labels and labels[tgt] <= k:
                     loops.append((k - labels[tgt], labels[tgt], k))
         print(sub, 'total', len(ins), dict(total))
-        for span, a, b in sorted(loops, reverse=True)[:3]:
+        for span, a, b in sorted(loops, reverse=True)[:8]:
             c = Counter(classify(i.split()[0]) for i in ins[a:b + 1])
             print('   loop span', span, dict(c))
 
