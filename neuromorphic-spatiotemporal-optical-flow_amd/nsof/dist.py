@@ -89,13 +89,15 @@ def run_sharded(prev_all, next_all, n_total, shape, device, compute, src=0):
 
 
 def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, chunk=32, src=0, compute_into=None,
-                           src_share=1.0, stats=None):
+                           src_share=1.0, stats=None, stage_frames=None):
     """scatter -> compute -> gather as a three-stage pipeline over chunks of every rank's shard, point to point
     (``dist.batch_isend_irecv``: ncclSend/ncclRecv pairs under RCCL, one xGMI link per peer, all peers of a round in one
     group) instead of the padded ``dist.scatter`` / ``dist.gather`` through rank ``src``: in round k the frames of chunk k
     travel to the peers while chunk k-1 computes and the flow of chunk k-2 travels back, so the links and the GPUs are
     busy together.  Staging is allocated ONCE (two frame and two flow buffers of one chunk per peer rank; rank ``src``
-    receives straight into the result) -- nothing is allocated inside the rounds when ``compute_into`` is given.
+    receives straight into the result; when its frames are not on ``device`` -- host memory -- rank ``src`` uploads
+    every chunk into two preallocated frame buffers per destination) -- nothing is allocated inside the rounds when
+    ``compute_into`` is given.  ``stage_frames``: force (True) or forbid (False) that upload staging; None = by device.
 
     ``prev_all`` / ``next_all``: uint8 [n_total, H, W] on rank ``src`` (ignored elsewhere).
     ``compute(prev, next) -> float32 [n, H, W, 2]`` on ``device``, or ``compute_into(prev, next, out)`` writing a
@@ -132,6 +134,25 @@ def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, 
         cap = max(b - a for a, b in my)
         frames = [torch.empty((2, cap, h, w), dtype=torch.uint8, device=device) for _ in range(2)]
         flows = [torch.empty((cap, h, w, 2), dtype=torch.float32, device=device) for _ in range(2)]
+    # rank src: frames that live elsewhere (host memory) go through two preallocated buffers per destination rank
+    # (its own chunks included); a send of round k has been waited for before round k + 1 starts, so two slots suffice
+    stage = None
+    if rank == src and n_total > 0:
+        if stage_frames is None:
+            stage_frames = prev_all.device != torch.device(device) or next_all.device != torch.device(device)
+        if stage_frames:
+            stage = {r: [torch.empty((2, max(b - a for a, b in chunks[r]), h, w), dtype=torch.uint8, device=device)
+                         for _ in range(2)] for r in range(world) if chunks[r]}
+
+    def staged(r, k):
+        """Frames of chunk k of rank r on ``device`` (rank src only): views of the source, or of the staging slot."""
+        a, b = chunks[r][k]
+        if stage is None:
+            return prev_all[a:b], next_all[a:b]
+        buf = stage[r][k & 1]
+        buf[0, :b - a].copy_(prev_all[a:b], non_blocking=True)
+        buf[1, :b - a].copy_(next_all[a:b], non_blocking=True)
+        return buf[0, :b - a], buf[1, :b - a]
 
     def run(pv, nx, dst):
         if compute_into is not None:
@@ -145,9 +166,9 @@ def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, 
         if rank == src:
             for r in range(world):
                 if r != src and k < len(chunks[r]):
-                    a, b = chunks[r][k]
-                    ops.append(dist.P2POp(dist.isend, prev_all[a:b].to(device).contiguous(), r))
-                    ops.append(dist.P2POp(dist.isend, next_all[a:b].to(device).contiguous(), r))
+                    pv, nx = staged(r, k)
+                    ops.append(dist.P2POp(dist.isend, pv, r))
+                    ops.append(dist.P2POp(dist.isend, nx, r))
         elif k < len(my):
             a, b = my[k]
             buf = frames[k & 1]
@@ -167,7 +188,8 @@ def run_sharded_overlapped(prev_all, next_all, n_total, shape, device, compute, 
         if 0 <= k - 1 < len(my):
             a, b = my[k - 1]
             if rank == src:
-                run(prev_all[a:b].to(device), next_all[a:b].to(device), out[a:b])
+                pv, nx = staged(src, k - 1)
+                run(pv, nx, out[a:b])
             else:
                 f = frames[(k - 1) & 1]
                 run(f[0, :b - a], f[1, :b - a], flows[(k - 1) & 1][:b - a])

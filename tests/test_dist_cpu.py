@@ -50,8 +50,11 @@ def _worker(rank, world, port, n_total, ret):
     # preallocated staging + compute_into; the sink rank with a smaller share / no share of the pairs; the stats record
     for share in (1.0, 0.5, 0.0):
         st = {}
+        # stage_frames: rank 0 uploads every chunk through its two preallocated buffers per destination (what it does
+        # when the frames are host memory and the ranks compute on GPUs)
         out3 = nd.run_sharded_overlapped(prev, nxt, n_total, (h, wd), "cpu", None, chunk=3, src_share=share, stats=st,
-                                         compute_into=lambda p_, q_, o_: o_.copy_(_fake_flow(p_, q_)))
+                                         compute_into=lambda p_, q_, o_: o_.copy_(_fake_flow(p_, q_)),
+                                         stage_frames=share != 1.0)
         assert st["backend"] == "gloo" and st["world_size"] == world and sum(st["pairs_per_rank"]) == n_total
         if share == 0.0 and world > 1:
             assert st["pairs_per_rank"][0] == 0 and st["pairs_moved"] == n_total
