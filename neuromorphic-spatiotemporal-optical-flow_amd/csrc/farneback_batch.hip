@@ -311,8 +311,11 @@ int het_core(nsof_ctx* ctx, int n, const nsof_pair_desc* descs, const Params& p)
                 if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_flow_upsample_het, c.count, dt + c.start, c.max_w, c.max_h, fb[cur],
                                        fb[cur ^ 1], (float)(1. / p.pyr_scale))))
                     return rc;
-                if ((rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_het, c.count, dt + c.start, ht + c.start, k == 0, btaps, dI))) return rc;
-                if ((rc = nsof_launch_polyexp_het(ctx, c.count, dt + c.start, c.max_w, c.max_h, ptaps, dI, dR))) return rc;
+                // level 0: the expansion kernel forms the level image from the frames itself (see nsof_farneback_core)
+                const bool u8 = k == 0 && btaps.ksize == 3 && !ctx->opt_pyr_fma && !ctx->opt_polyexp_f32;
+                const float blur3[2] = {btaps.k[1], btaps.k[2]};
+                if (!u8 && (rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_het, c.count, dt + c.start, ht + c.start, k == 0, btaps, dI))) return rc;
+                if ((rc = nsof_launch_polyexp_het(ctx, c.count, dt + c.start, c.max_w, c.max_h, ptaps, dI, dR, u8 ? blur3 : nullptr))) return rc;
             }
             cur ^= 1;
             for (int it = 0; it < p.iterations; it++) {

@@ -244,33 +244,39 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
 
     float ring[RING][NC];
 
-    // row filter of (unreflected) source row r at this lane's sampled columns -> ring[slot]
-    auto load_row = [&](int r, float (&dstrow)[NC]) {
+    // A source row as loaded: the lane's CW bytes + HB halo bytes per side.  fetch() only issues the loads, filt()
+    // evaluates the row filter at this lane's sampled columns -> ring[slot]; between the two a row can stay in flight
+    // while the rows before it are filtered (S <= 4: the rows of the NEXT output row are fetched before this one's are
+    // used -- with one output row's 2 or 4 source rows in flight per wave the kernel waited for memory half the time).
+    struct Raw {
+        unsigned cw[CW / 4], hl[HD], hr[HD];
+    };
+    auto fetch = [&](int r, Raw& q) {
         const uint8_t* rowp = img + (ptrdiff_t)reflect101(r, H) * row_stride + xc0;
-        unsigned cw[CW / 4];
         if (CW == 16) {
             const uint4 c = *reinterpret_cast<const uint4*>(rowp);
-            cw[0] = c.x; cw[1] = c.y; cw[(CW / 4 > 2) ? 2 : 0] = c.z; cw[(CW / 4 > 3) ? 3 : 0] = c.w;
+            q.cw[0] = c.x; q.cw[1] = c.y; q.cw[(CW / 4 > 2) ? 2 : 0] = c.z; q.cw[(CW / 4 > 3) ? 3 : 0] = c.w;
         } else {
             const uint2 c = *reinterpret_cast<const uint2*>(rowp);
-            cw[0] = c.x; cw[1] = c.y;
+            q.cw[0] = c.x; q.cw[1] = c.y;
         }
-        unsigned hl[HD], hr[HD];
         const uint8_t* lp = edge_l ? rowp : rowp - HB;          // edge lanes: any valid address, value unused
         const uint8_t* rp = edge_r ? rowp : rowp + CW;
 #pragma unroll
         for (int d = 0; d < HD; d++) {
-            hl[d] = reinterpret_cast<const unsigned*>(lp)[d];
-            hr[d] = reinterpret_cast<const unsigned*>(rp)[d];
+            q.hl[d] = reinterpret_cast<const unsigned*>(lp)[d];
+            q.hr[d] = reinterpret_cast<const unsigned*>(rp)[d];
         }
+    };
+    auto filt = [&](const Raw& q, float (&dstrow)[NC]) {
         float raw[WIN];   // window [xc0 - HB, xc0 + CW + HB) as loaded
 #pragma unroll
         for (int b = 0; b < HB; b++) {
-            raw[b] = (float)((hl[b >> 2] >> (8 * (b & 3))) & 0xffu);
-            raw[HB + CW + b] = (float)((hr[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            raw[b] = (float)((q.hl[b >> 2] >> (8 * (b & 3))) & 0xffu);
+            raw[HB + CW + b] = (float)((q.hr[b >> 2] >> (8 * (b & 3))) & 0xffu);
         }
 #pragma unroll
-        for (int b = 0; b < CW; b++) raw[HB + b] = (float)((cw[b >> 2] >> (8 * (b & 3))) & 0xffu);
+        for (int b = 0; b < CW; b++) raw[HB + b] = (float)((q.cw[b >> 2] >> (8 * (b & 3))) & 0xffu);
         float fb[WIN];
 #pragma unroll
         for (int b = 0; b < CW; b++) fb[HB + b] = raw[HB + b];
@@ -284,23 +290,48 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
 #pragma unroll
         for (int n = 0; n < NC; n++) {
             const int off = HB + S * (n >> 1) + S / 2 - 1 + (n & 1);
-            dstrow[n] = row_filter<KS>(tk, KS, off, [&](int q) { return fb[q]; });
+            dstrow[n] = row_filter<KS>(tk, KS, off, [&](int q2) { return fb[q2]; });
         }
     };
+    auto load_row = [&](int r, float (&dstrow)[NC]) {
+        Raw q;
+        fetch(r, q);
+        filt(q, dstrow);
+    };
+#ifndef NSOF_DECIM_PF
+#define NSOF_DECIM_PF 4
+#endif
+    constexpr bool PF = S <= NSOF_DECIM_PF;   // prefetch one output row ahead
 
     // relative row index rel = r - base, base = first row needed by output row dy0; slot = rel % RING
     const int base = S * dy0 + S / 2 - 1 - R;
 #pragma unroll
     for (int i = 0; i <= KS - S; i++) load_row(base + i, ring[i % RING]);
 
+    Raw nx[PF ? S : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int i = 0; i < S; i++) fetch(base + KS - S + 1 + i, nx[i]);
+    }
     for (int g = 0; dy0 + g * U < dy1; g++) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int dy = dy0 + g * U + u;
             if (dy >= dy1) break;                               // wave-uniform
+            if constexpr (PF) {
+                Raw cu[S];
 #pragma unroll
-            for (int i = 0; i < S; i++) {
-                load_row(base + S * (g * U + u) + KS - S + 1 + i, ring[(S * u + KS - S + 1 + i) % RING]);
+                for (int i = 0; i < S; i++) cu[i] = nx[i];
+                // the next output row's source rows (beyond the segment: reflected rows of the image, never used)
+#pragma unroll
+                for (int i = 0; i < S; i++) fetch(base + S * (g * U + u + 1) + KS - S + 1 + i, nx[i]);
+#pragma unroll
+                for (int i = 0; i < S; i++) filt(cu[i], ring[(S * u + KS - S + 1 + i) % RING]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    load_row(base + S * (g * U + u) + KS - S + 1 + i, ring[(S * u + KS - S + 1 + i) % RING]);
+                }
             }
             if (live) {
                 float o[NPX];
@@ -1089,13 +1120,26 @@ __global__ __launch_bounds__(256) void k_polyexp(const float* __restrict__ img, 
 // pass (the column window of 2N+1 rows on one side, the moment window and the double taps on the other), so the
 // taps stay in scalar registers and radius 10 fits 4 waves per SIMD where the single-role kernel spilled at 256.
 // ---------------------------------------------------------------------------------------
-template <int N, bool HET>
+// U8 (the full-resolution level): the level image is not read from memory but formed in the vertical pass from the
+// 8-bit frame itself -- the 3 x 3 [k1 k0 k1] smoothing of k_prep_same3_vec, operation for operation -- so the
+// pyramid kernel of level 0 and the 8 B/px its image costs (written there, read here) disappear; the vertical-pass
+// waves have the issue slots for it (187 of their step's ~500 instruction slots were used).
+struct PolyU8 {
+    const uint8_t* src0;   // images [0, nsplit) at src0 + z * img_stride, the others at src1 + (z - nsplit) * img_stride
+    const uint8_t* src1;
+    long long row_stride, img_stride;
+    int nsplit;
+    float k0, k1;          // centre and side tap
+};
+template <int N, bool HET, bool U8 = false>
 __global__ __launch_bounds__(512) void k_polyexp_rs(const float* __restrict__ img, float* __restrict__ R, int W, int H,
                                                      int seg_rows, nsof_poly_taps tp,
-                                                     const nsof_het_item* __restrict__ items)
+                                                     const nsof_het_item* __restrict__ items, PolyU8 u8 = PolyU8{})
 {
     using G = PolyGeom<N>;
     size_t img_off, r_off;   // element offsets of this image / its expansion
+    const uint8_t* sb = nullptr;   // U8: this image's frame
+    long long srs = 0;
     if constexpr (HET) {
         const nsof_het_item& it = items[blockIdx.z >> 1];
         const size_t which = blockIdx.z & 1;
@@ -1104,9 +1148,18 @@ __global__ __launch_bounds__(512) void k_polyexp_rs(const float* __restrict__ im
         if (blockIdx.x * G::SW >= W || blockIdx.y * seg_rows >= H) return;   // block-uniform, before any barrier
         img_off = it.offI + which * (size_t)W * H;
         r_off = it.offR + which * 5 * (size_t)W * H;
+        if constexpr (U8) {
+            sb = it.src[which];
+            srs = it.src_stride[which];
+        }
     } else {
         img_off = (size_t)blockIdx.z * W * H;
         r_off = (size_t)blockIdx.z * 5 * W * H;
+        if constexpr (U8) {
+            const int z = blockIdx.z;
+            sb = z < u8.nsplit ? u8.src0 + (ptrdiff_t)z * u8.img_stride : u8.src1 + (ptrdiff_t)(z - u8.nsplit) * u8.img_stride;
+            srs = u8.row_stride;
+        }
     }
     __shared__ __attribute__((aligned(16))) float sr[2][3][4][256];
     __shared__ float4 st[4][256];   // per-wave transpose buffer for the interleaved channel-0..3 stores
@@ -1125,18 +1178,61 @@ __global__ __launch_bounds__(512) void k_polyexp_rs(const float* __restrict__ im
         auto ld = [&](int row) {
             return *reinterpret_cast<const float*>(Ib + ((unsigned)clampi(row, 0, H - 1) * (unsigned)W + (unsigned)xc) * 4u);
         };
+        // U8: I[rc][xc] from the frame.  The rows are asked for in order, so the row-filtered values of rows rc - 1, rc,
+        // rc + 1 (reflected at the image border like the pyramid kernel's) are kept and one new row is filtered per
+        // new rc; fetch3() only issues the loads of a row's three bytes (four rows ahead, like the float loads).
+        const int xl = U8 ? reflect101(xc - 1, W) : 0, xr = U8 ? reflect101(xc + 1, W) : 0;
+        struct Raw3 {
+            unsigned l, c, r;
+        };
+        auto fetch3 = [&](int srow) {   // srow: a row of the frame
+            const uint8_t* rp = sb + (ptrdiff_t)srow * srs;
+            return Raw3{rp[xl], rp[xc], rp[xr]};
+        };
+        auto hval = [&](const Raw3& q) { return NSOF_MADD((float)q.l + (float)q.r, u8.k1, (float)q.c * u8.k0); };
+        int rc_cur = 0;
+        float hm = 0.f, h0 = 0.f, hp = 0.f, icur = 0.f;
+        auto below = [&](int row) { return reflect101(clampi(row, 0, H - 1) + 1, H); };   // the frame row under clamp(row)
+        auto advance = [&](int row, const Raw3& under) {   // I[clamp(row)][xc]; under = fetch3(below(row))
+            const int rc = clampi(row, 0, H - 1);
+            if (rc != rc_cur) {   // block-uniform; rows come in order: rc == rc_cur + 1
+                hm = h0;
+                h0 = hp;
+                hp = hval(under);
+                icur = NSOF_MADD(hm + hp, u8.k1, h0 * u8.k0);
+                rc_cur = rc;
+            }
+            return icur;
+        };
         float win[2 * N + 1];   // win[j] = I[clamp(y - N + j)][xc]
-#pragma unroll
-        for (int j = 0; j <= 2 * N; j++) win[j] = ld(ys - N + j);
         float pre[4];
+        Raw3 praw[4];
+        if constexpr (U8) {
+            rc_cur = clampi(ys - N, 0, H - 1);
+            hm = hval(fetch3(reflect101(rc_cur - 1, H)));
+            h0 = hval(fetch3(rc_cur));
+            hp = hval(fetch3(reflect101(rc_cur + 1, H)));
+            icur = NSOF_MADD(hm + hp, u8.k1, h0 * u8.k0);
+            win[0] = icur;
 #pragma unroll
-        for (int q = 0; q < 4; q++) pre[q] = ld(ys + 1 + N + q);
+            for (int j = 1; j <= 2 * N; j++) win[j] = advance(ys - N + j, fetch3(below(ys - N + j)));
+#pragma unroll
+            for (int q = 0; q < 4; q++) pre[q] = advance(ys + 1 + N + q, fetch3(below(ys + 1 + N + q)));
+        } else {
+#pragma unroll
+            for (int j = 0; j <= 2 * N; j++) win[j] = ld(ys - N + j);
+#pragma unroll
+            for (int q = 0; q < 4; q++) pre[q] = ld(ys + 1 + N + q);
+        }
         for (int t = 0; t <= nsteps; t++) {
             if (t < nsteps) {
                 const int y = ys + 4 * t, buf = t & 1;
                 float nxt[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) nxt[q] = ld(y + 5 + N + q);
+                for (int q = 0; q < 4; q++) {
+                    if constexpr (U8) praw[q] = fetch3(below(y + 5 + N + q));
+                    else nxt[q] = ld(y + 5 + N + q);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     float t0 = win[N] * tp.g[0], t1 = 0.f, t2 = 0.f;
@@ -1157,7 +1253,10 @@ __global__ __launch_bounds__(512) void k_polyexp_rs(const float* __restrict__ im
                     win[2 * N] = pre[q];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) pre[q] = nxt[q];
+                for (int q = 0; q < 4; q++) {
+                    if constexpr (U8) pre[q] = advance(y + 5 + N + q, praw[q]);
+                    else pre[q] = nxt[q];
+                }
             }
             __syncthreads();
         }
@@ -1685,7 +1784,8 @@ __global__ __launch_bounds__(256) void k_flow_upsample_walk(const float* __restr
 }
 
 template <int N>
-void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R)
+void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R,
+                      const PolyU8* u8 = nullptr)
 {
     using G = PolyGeom<N>;
     const int strips = (W + G::SW - 1) / G::SW;
@@ -1700,7 +1800,9 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
 #ifdef NSOF_AB
     static const bool mono = [] { const char* e = NSOF_AB_GETENV("NSOF_POLYEXP"); return e && e[0] == 'm'; }();   // A/B: single-role kernel
 #endif
-    if (ctx->opt_polyexp_f32)
+    if (u8)
+        hipLaunchKernelGGL((k_polyexp_rs<N, false, true>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, nullptr, *u8);
+    else if (ctx->opt_polyexp_f32)
         hipLaunchKernelGGL((k_polyexp<N, false, true>), grid, dim3(256), 0, ctx->stream, img, R, W, H, seg_rows, taps,
                            nullptr);
 #ifdef NSOF_AB   // NSOF_POLYEXP=mono: the single-role kernel with the exact arithmetic (superseded by k_polyexp_rs)
@@ -1714,7 +1816,7 @@ void launch_polyexp_n(nsof_ctx* ctx, int n_img, const float* img, int W, int H, 
 // Work-list twin: W, H are the largest level extents over the table, n_img = 2 * items.
 template <int N>
 void launch_polyexp_het_n(nsof_ctx* ctx, int n_img, const nsof_het_item* items, const float* img, int W, int H,
-                          const nsof_poly_taps& taps, float* R)
+                          const nsof_poly_taps& taps, float* R, const PolyU8* u8 = nullptr)
 {
     using G = PolyGeom<N>;
     const int strips = (W + G::SW - 1) / G::SW;
@@ -1723,7 +1825,8 @@ void launch_polyexp_het_n(nsof_ctx* ctx, int n_img, const nsof_het_item* items, 
     int seg_rows = ((H + segs - 1) / segs + 3) / 4 * 4;
     segs = (H + seg_rows - 1) / seg_rows;
     dim3 grid(strips, segs, n_img);
-    hipLaunchKernelGGL((k_polyexp_rs<N, true>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, items);
+    if (u8) hipLaunchKernelGGL((k_polyexp_rs<N, true, true>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, items, *u8);
+    else hipLaunchKernelGGL((k_polyexp_rs<N, true>), grid, dim3(512), 0, ctx->stream, img, R, W, H, seg_rows, taps, items);
 }
 
 }  // namespace
@@ -1859,6 +1962,23 @@ int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src
 }
 
 #ifndef NSOF_PYR_FMA
+// The expansion of the full-resolution level straight from the 8-bit frames (k_polyexp_rs<.., U8>): images [0, nsplit)
+// at src0 + z * img_stride, the rest at src1; k0 / k1 = centre / side tap of the level's 3-tap smoothing.
+int nsof_launch_polyexp_u8(nsof_ctx* ctx, int n_img, const uint8_t* src0, const uint8_t* src1, int nsplit, ptrdiff_t row_stride,
+                           ptrdiff_t img_stride, int W, int H, const nsof_poly_taps& taps, float k0, float k1, float* R)
+{
+    nsof_prof_scope ps(ctx, NSOF_K_POLYEXP);
+    const PolyU8 u8{src0, src1, (long long)row_stride, (long long)img_stride, nsplit, k0, k1};
+    switch (taps.n) {
+#define NSOF_PU(NN) case NN: launch_polyexp_n<NN>(ctx, n_img, nullptr, W, H, taps, R, &u8); break
+        NSOF_PU(1); NSOF_PU(2); NSOF_PU(3); NSOF_PU(4); NSOF_PU(5); NSOF_PU(6); NSOF_PU(7); NSOF_PU(8); NSOF_PU(9); NSOF_PU(10);
+#undef NSOF_PU
+        default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "poly_n=%d outside 1..%d", taps.n, NSOF_MAX_POLY_N);
+    }
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
 int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps, float* R)
 {
     nsof_prof_scope ps(ctx, NSOF_K_POLYEXP);
@@ -2008,13 +2128,18 @@ int NSOF_PYR_NAME(nsof_launch_prep_het)(nsof_ctx* ctx, int n_items, const nsof_h
 }
 
 #ifndef NSOF_PYR_FMA
+// blur3: non-null at the full-resolution level = form the level image from the items' own frames (k0, k1 = centre / side
+// tap); I is not read then.
 int nsof_launch_polyexp_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
-                            const nsof_poly_taps& taps, const float* I, float* R)
+                            const nsof_poly_taps& taps, const float* I, float* R, const float* blur3)
 {
     nsof_prof_scope ps(ctx, NSOF_K_POLYEXP);
     const int nz = 2 * n_items;
+    PolyU8 u8v{};
+    if (blur3) { u8v.k0 = blur3[0]; u8v.k1 = blur3[1]; }
+    const PolyU8* u8 = blur3 ? &u8v : nullptr;
     switch (taps.n) {
-#define NSOF_PH(NN) case NN: launch_polyexp_het_n<NN>(ctx, nz, d_items, I, max_w, max_h, taps, R); break
+#define NSOF_PH(NN) case NN: launch_polyexp_het_n<NN>(ctx, nz, d_items, I, max_w, max_h, taps, R, u8); break
         NSOF_PH(1); NSOF_PH(2); NSOF_PH(3); NSOF_PH(4); NSOF_PH(5); NSOF_PH(6); NSOF_PH(7); NSOF_PH(8); NSOF_PH(9); NSOF_PH(10);
 #undef NSOF_PH
         default: return nsof_set_error(ctx, NSOF_EUNSUPPORTED, "poly_n=%d outside 1..%d", taps.n, NSOF_MAX_POLY_N);

@@ -812,6 +812,21 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         return NSOF_OK;
     };
 
+    // Level 0 (the frame's own size, 3-tap smoothing): the expansion kernel forms the level image itself from the 8-bit
+    // frames (k_polyexp_rs<.., U8>): no pyramid launch, no image written and read back.  Not with the FMA twin of the
+    // pyramid stages nor with the float expansion (their kernels have no such form).
+    static const bool poly_u8_off = [] { const char* e = NSOF_AB_GETENV("NSOF_POLY_U8"); return e && e[0] == '0'; }();
+    const bool poly_u8 = !poly_u8_off && !ctx->opt_pyr_fma && !ctx->opt_polyexp_f32 && width >= 2 && height >= 2;
+    auto level_expansion = [&](int k, int wk, int hk, const nsof_blur_taps& bt, float* I, float* Rk) -> int {
+        if (poly_u8 && k == 0 && bt.ksize == 3 && wk == width && hk == height) {
+            const bool one = sequence || prep_merged;
+            return nsof_launch_polyexp_u8(ctx, (int)n_img, d_prev, one ? d_prev : d_next, one ? (int)n_img : n_pairs, row_stride,
+                                          pair_stride, width, height, ptaps, bt.k[1], bt.k[2], Rk);
+        }
+        if (int r = prep_level(wk, hk, bt, I)) return r;
+        return nsof_launch_polyexp(ctx, (int)n_img, I, wk, hk, ptaps, Rk);
+    };
+
     // ---- small batches (the three-kernel exact form): the latency schedule ---------------------------------------------
     // A lone call is a chain of ~50 launches that each use a fraction of the chip and cost >= ~5 us (profiles/
     // r03_lone_call_timeline.txt: 762 us at 1080p, a third of it in the two coarsest levels).  Only the FLOW couples the
@@ -853,9 +868,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
             nsof_blur_taps bt;
             if (int r = nsof_host_blur_taps(ks, sg, &bt))
                 return nsof_set_error(ctx, r, "pyramid blur kernel size %d unsupported (max %d)", ks, NSOF_MAX_BLUR_TAPS - 1);
-            float* I = (float*)(base + offI[k]);
-            if (int r = prep_level(wk, hk, bt, I)) return r;
-            return nsof_launch_polyexp(ctx, (int)n_img, I, wk, hk, ptaps, (float*)(base + totI + offR[k]));
+            return level_expansion(k, wk, hk, bt, (float*)(base + offI[k]), (float*)(base + totI + offR[k]));
         };
         const hipStream_t mainS = ctx->stream, sideS = ctx->side;
         NSOF_HIP(ctx, hipEventRecord(ctx->ov_events[L + 1], mainS));            // the frames are on the device; earlier calls are done
@@ -919,8 +932,7 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         }
         // image-major: dI [n_img][hk][wk], dR [n_img][5*hk*wk].  Pairs: all prev frames then all next frames
         // (R1 = R0 + B images); sequence: the frames in order (R1 = R0 + 1 image).
-        if ((rc = prep_level(wk, hk, btaps, dI))) return rc;
-        if ((rc = nsof_launch_polyexp(ctx, (int)n_img, dI, wk, hk, ptaps, dR))) return rc;
+        if ((rc = level_expansion(k, wk, hk, btaps, dI, dR))) return rc;
         const float* R0 = dR;
         const float* R1 = dR + (sequence ? (size_t)1 : B) * 5 * nk;
         if (fused) {

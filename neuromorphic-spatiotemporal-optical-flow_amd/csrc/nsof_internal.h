@@ -173,7 +173,7 @@ int nsof_launch_iterate_het_exact(nsof_ctx* ctx, int n_items, const nsof_het_ite
 int nsof_launch_prep_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
                          bool level0, const nsof_blur_taps& taps, float* I);
 int nsof_launch_polyexp_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
-                            const nsof_poly_taps& taps, const float* I, float* R);
+                            const nsof_poly_taps& taps, const float* I, float* R, const float* blur3 = nullptr);
 int nsof_launch_flow_upsample_het(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, int max_w, int max_h,
                                   const float* src, float* dst, float mul);
 // final: the flow goes to the items' own output fields (out / out_pitch) instead of flow_out.
@@ -193,6 +193,9 @@ int nsof_launch_flow_upsample_het_fma(nsof_ctx* ctx, int n_items, const nsof_het
                                       const float* src, float* dst, float mul);
 int nsof_launch_polyexp(nsof_ctx* ctx, int n_img, const float* img, int W, int H, const nsof_poly_taps& taps,
                         float* R);
+// Full-resolution level: pyramid level (3-tap smoothing, centre k0 / side k1) + expansion in one kernel, from the frames.
+int nsof_launch_polyexp_u8(nsof_ctx* ctx, int n_img, const uint8_t* src0, const uint8_t* src1, int nsplit, ptrdiff_t row_stride,
+                           ptrdiff_t img_stride, int W, int H, const nsof_poly_taps& taps, float k0, float k1, float* R);
 // R0/R1: planar [5][h][w] expansion of prev/next of pair 0; pair z is at +z*pair_stride floats.
 int nsof_launch_update_matrices(nsof_ctx* ctx, int n_pairs, const float* R0, const float* R1, size_t pair_stride,
                                 const float* flow, int W, int H, float* M);

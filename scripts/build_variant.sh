@@ -8,7 +8,7 @@ name=$1; src=$2; flags=$3
 make -s
 mkdir -p build/var_$name
 base=$(basename "$src" .hip)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-value \
     -Wno-unused-result -DNSOF_AB -I../include -Icsrc $flags -c csrc/$base.hip -o build/var_$name/$base.o
 objs=""
 for o in build/*.o; do
