@@ -80,16 +80,21 @@ def level_sizes(nsof, w, h, p):
     return [nsof.level_size(w, h, p.pyr_scale, k)[:2] for k in range(L + 1)]
 
 
-def algorithmic_bytes_per_pair(nsof, w, h, p):
-    """Per-kernel compulsory HBM bytes for ONE frame pair."""
+def algorithmic_bytes_per_pair(nsof, w, h, p, fused_level0=True):
+    """Per-kernel compulsory HBM bytes for ONE frame pair.
+    fused_level0: the default path forms the full-resolution level image inside the expansion kernel (no pyramid launch
+    at level 0, 1 B instead of 4 B read per pixel there); the float-expansion mode keeps the two kernels."""
     from nsof import _lib
     sizes = level_sizes(nsof, w, h, p)
     n0 = w * h
     out = {k: 0 for k in range(_lib.K_COUNT)}
     for k, (wk, hk) in enumerate(sizes):
         nk = wk * hk
-        out[_lib.K_PREP] += 2 * (n0 + 4 * nk)                  # u8 frame in, f32 level image out, x2 frames
-        out[_lib.K_POLYEXP] += 2 * 24 * nk                     # 4 B read + 5x4 B written per pixel, x2 frames
+        if k == 0 and fused_level0:
+            out[_lib.K_POLYEXP] += 2 * 21 * nk                 # 1 B read (the frame) + 5x4 B written per pixel, x2 frames
+        else:
+            out[_lib.K_PREP] += 2 * (n0 + 4 * nk)              # u8 frame in, f32 level image out, x2 frames
+            out[_lib.K_POLYEXP] += 2 * 24 * nk                 # 4 B read + 5x4 B written per pixel, x2 frames
         out[_lib.K_UPDMAT] += p.iterations * 68 * nk           # R0 20 + R1 20 + flow 8 -> M 20
         out[_lib.K_BLUR] += p.iterations * 28 * nk             # M 20 -> flow 8
         out[_lib.K_ITERATE] += p.iterations * 56 * nk          # fused: R0 20 + R1 20 + flow 8 -> flow 8
@@ -230,7 +235,7 @@ def main():
         total_pairs = n * world * args.steps
         alg = algorithmic_bytes_per_pair(nsof, w, h, p)
 
-        def roof(kid, prof=prof, steps=args.steps):
+        def roof(kid, prof=prof, steps=args.steps, alg=alg):
             ms, launches = prof[kid]
             if not launches:
                 return None
@@ -262,6 +267,17 @@ def main():
             dom = max(kernel_ids, key=lambda k: prof[k][0])
             out["roofline"] = roof(dom)
             out["roofline_polyexp"] = roof(_lib.K_POLYEXP)
+            if out["roofline_polyexp"] and prof[_lib.K_POLYEXP][1]:
+                # The expansion kernel of level 0 also does the level-0 pyramid stage's work (no such launch any more).
+                # frac above prices the FUSED kernel's compulsory bytes (21 B/px there); on the separate stages' bytes
+                # (24 B/px expansion + the pyramid stage's 5 B/px of level 0) the same launches read:
+                alg_sep = algorithmic_bytes_per_pair(nsof, w, h, p, fused_level0=False)
+                sep = (alg_sep[_lib.K_POLYEXP] + 2 * 5 * w * h) * n * args.steps
+                ms_p = prof[_lib.K_POLYEXP][0]
+                out["roofline_polyexp"]["separate_stage_bytes"] = {
+                    "bytes_per_launch": int(sep / prof[_lib.K_POLYEXP][1]), "achieved": round(sep / (ms_p * 1e-3) / 1e9, 1),
+                    "unit": "GB/s", "frac": round(sep / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "24 B/px expansion + 5 B/px level-0 pyramid stage: what these launches replace"}
             out["kernel_ms_per_step"] = {_lib.load().nsof_kernel_name(k).decode(): round(prof[k][0] / args.steps, 3)
                                          for k in kernel_ids}
             tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived HBM bytes (see its _doc)
@@ -388,7 +404,7 @@ def fast_polyexp_leg(nsof, _lib, ctx, torch, p, prevs, nexts, flow, n, h, w, alg
         ctx.set_option(_lib.OPT_POLYEXP_F32, 0)
     prof = dict(prof)
     prof[_lib.K_POLYEXP] = (ms, launches)
-    r = roof_of(_lib.K_POLYEXP, prof, steps)
+    r = roof_of(_lib.K_POLYEXP, prof, steps, algorithmic_bytes_per_pair(nsof, w, h, p, fused_level0=False))
     diff = float((flow_fast - flow).abs().max().item())
     per_pair = (flow_fast - flow).abs().amax(dim=(1, 2, 3))
     return {"roofline_polyexp_fast": r, "fast_mode": {

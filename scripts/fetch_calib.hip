@@ -40,6 +40,23 @@ __global__ __launch_bounds__(256) void k_rows_10_per_8(const unsigned char* __re
     if (acc == 0x12345678u) *sink = acc;
 }
 
+// The pattern of the vertical pass of k_polyexp_rs<.., U8>: a thread owns a column of a 240-column strip (+ 8 halo columns per
+// side, so neighbouring strips overlap by 16) and walks down a 64-row segment (+ 6 rows of warm-up per side) reading the bytes
+// at x - 1, x, x + 1 of every row with three byte loads.
+__global__ __launch_bounds__(256) void k_bytes_3_per_px(const unsigned char* __restrict__ img, int W, int H, unsigned* sink)
+{
+    const int x = min(max((int)blockIdx.x * 240 - 8 + (int)threadIdx.x, 0), W - 1);
+    const int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+    const int y0 = blockIdx.y * 64;
+    const unsigned char* p = img + (size_t)blockIdx.z * W * H;
+    unsigned acc = 0;
+    for (int r = y0 - 6; r < y0 + 64 + 6; r++) {
+        const unsigned char* rp = p + (size_t)min(max(r, 0), H - 1) * W;
+        acc += rp[xl] + rp[x] + rp[xr];
+    }
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 int main()
 {
     const size_t bytes = (size_t)1 << 30;
@@ -57,6 +74,8 @@ int main()
         const int W = 1920, H = 1080, n = (int)(bytes / ((size_t)W * H));   // 517 frames
         for (int rep = 0; rep < 3; rep++)
             hipLaunchKernelGGL(k_rows_10_per_8, dim3((W / 4 + 63) / 64, (H + 31) / 32, n), dim3(256), 0, 0, (const unsigned char*)buf, W, H, sink);
+        for (int rep = 0; rep < 3; rep++)
+            hipLaunchKernelGGL(k_bytes_3_per_px, dim3((W + 239) / 240, (H + 63) / 64, n), dim3(256), 0, 0, (const unsigned char*)buf, W, H, sink);
         printf("rows pattern: %d frames, %zu frame bytes per launch\n", n, (size_t)n * W * H);
     }
     if (hipDeviceSynchronize() != hipSuccess) return 2;

@@ -30,6 +30,15 @@ if rows:
                                            "fetch_x2_over_frame_bytes": round(2 * m * 1024 / fb, 4),
                                            "note": "the level-0 pyramid kernel's read pattern: with the x2 of the streaming calibration the fabric "
                                                    "sees this multiple of the frame bytes (1.0 = the L2 absorbs the row overlap, 1.25 = none of it)"}
+rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if r["Counter_Name"] == "FETCH_SIZE" and "k_bytes_3_per_px" in r["Kernel_Name"]]
+if rows:
+    fb = 517 * 1920 * 1080
+    m = sum(rows[1:]) / len(rows[1:])
+    out["bytes_3_per_px"] = {"frame_bytes": fb, "fetch_size_kib": round(m, 1), "fetch_x2_over_frame_bytes": round(2 * m * 1024 / fb, 4),
+                             "fetch_x1_over_frame_bytes": round(m * 1024 / fb, 4),
+                             "note": "the read pattern of the vertical pass of k_polyexp_rs<.., U8> (three byte loads per row and column, "
+                                     "strips overlapping by 16 of 256 columns, segments by 12 of 76 rows): which multiple of the frame bytes "
+                                     "the fabric sees with the counter doubled (x2) and as it is (x1)"}
 json.dump(out, open(f"{repo}/gpurun_out/fetch_calibration.json", "w"), indent=1)
-print(json.dumps(out["widths"])); print(json.dumps(out.get("rows_10_per_8_dword_per_lane")))
+print(json.dumps(out["widths"])); print(json.dumps(out.get("rows_10_per_8_dword_per_lane"))); print(json.dumps(out.get("bytes_3_per_px")))
 PY
