@@ -210,6 +210,24 @@ def test_skewed_work_list_equals_per_call(nsof_lib, ctx, small_batch_jobs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("params", [A, (0.6, 3, 3, 3, 10, 1.05, 0), (0.6, 3, 4, 2, 1, 1.05, 0), (0.5, 2, 9, 2, 7, 1.5, 0)])
+def test_small_item_lists_equal_per_call(nsof_lib, ctx, params):
+    """Two hundred small items (2..140 rows, 2..140 columns: strips a third full, jobs of a few steps, several size
+    classes) in one list, four parameter sets: every flow equal to the lone call's."""
+    nsof = nsof_lib
+    p = nsof.FarnebackParams(*params)
+    rng = np.random.default_rng(5)
+    shapes = [(64, 64), (65, 65), (63, 200), (200, 63), (9, 64), (300, 64), (128, 128), (129, 127), (2, 2), (3, 64), (64, 3)]
+    shapes += [(int(rng.integers(2, 140)), int(rng.integers(2, 70))) for _ in range(150)]
+    shapes += [(int(rng.integers(20, 200)), int(rng.integers(60, 140))) for _ in range(40)]
+    pairs = _crops(17, shapes, frame_hw=(400, 500))
+    got = nsof.farneback_pairs(pairs, p, ctx=ctx)
+    for (a, b), g in zip(pairs, got):
+        want = nsof.calcOpticalFlowFarneback(a, b, None, **p.as_kwargs(), ctx=ctx)
+        assert np.array_equal(g, want), (a.shape, float(np.abs(g - want).max()))
+
+
+@pytest.mark.gpu
 def test_work_list_vs_oracle_and_canvas_paste(nsof_lib, ctx, oracle):
     """ROI flows written in place into frame-sized canvases (the paste of optical_flow_seg.py:162/204), pinned and
     pageable targets, several pipeline chunks; compared with the CPU oracle."""
