@@ -442,6 +442,10 @@ def params_leg(nsof, _lib, ctx, torch, q, prevs, nexts, flow, k, h, w, kernel_id
             rec["roofline"][name(kid).decode()] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                                                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                                    "avg_launch_us": round(ms * 1e3 / launches, 2)}
+    if name(_lib.K_PREP).decode() in rec["roofline"]:
+        rec["roofline"][name(_lib.K_PREP).decode()]["note"] = (
+            "levels 1..L only (the generic-scale walk kernels, each re-reading the full frame): level 0 has no pyramid "
+            "launch any more, the expansion kernel forms its image from the frame")
     fused = sum(alg[kid] for kid in kernel_ids if prof[kid][1])
     rec["fused_algorithmic_GBps"] = round(fused * k * steps / dt / 1e9, 1)
     rec["frac_of_hbm_peak"] = round(fused * k * steps / dt / 1e9 / HBM_PEAK_GBS, 4)
