@@ -217,10 +217,11 @@ __global__ __launch_bounds__(256) void k_prep_same3_vec(const uint8_t* __restric
 //     over RING / S steps),
 //   * column filter at the two sampled rows, then resize's 2x2 blend (all four weights are exactly 0.5).
 // Same operation order as the other prep kernels (row_filter / col_filter), so the output is bit-identical.
+// The walk of one wave: column group `bx * 64 + lane`, output rows [seg * seg_rows, (seg + 1) * seg_rows) of image z.
 template <int S, int KS, int CW>
-__global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
-                                                     ptrdiff_t img_stride, int W, int H, int wk, int hk, int seg_rows,
-                                                     nsof_blur_taps t, float* __restrict__ out)
+__device__ __forceinline__ void prep_decim_body(const uint8_t* __restrict__ src, ptrdiff_t row_stride, ptrdiff_t img_stride,
+                                                int W, int H, int wk, int hk, int seg_rows, const nsof_blur_taps& t,
+                                                float* __restrict__ out, int bx, int seg, int z)
 {
     // CW = source columns per lane: 16 (one 16-B load per row) when W % 16 == 0, else 8 (W % 8 == 0, e.g. the
     // 1080-wide portrait frames of the reference's grasp sequence)
@@ -229,17 +230,16 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
     constexpr int HB = (R + 3) / 4 * 4, HD = HB / 4;          // halo bytes / dwords per side
     constexpr int WIN = HB + CW + HB;
     static_assert(NPX >= 1, "lane narrower than one output pixel");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int T = blockIdx.x * 64 + lane;                      // CW-column group
-    const int seg = blockIdx.y * 4 + wave;
+    const int lane = threadIdx.x & 63;
+    const int T = bx * 64 + lane;                              // CW-column group
     const int dy0 = seg * seg_rows;
     if (dy0 >= hk) return;                                     // wave-uniform
     const int dy1 = min(dy0 + seg_rows, hk);
     const bool live = CW * T < W;
     const int xc0 = live ? CW * T : 0;
     const bool edge_l = xc0 == 0, edge_r = xc0 + CW >= W;
-    const uint8_t* img = src + (ptrdiff_t)blockIdx.z * img_stride;
-    float* dst = out + (size_t)blockIdx.z * wk * hk;
+    const uint8_t* img = src + (ptrdiff_t)z * img_stride;
+    float* dst = out + (size_t)z * wk * hk;
     auto tk = [&](int j) { return t.k[j]; };                   // static index after unrolling
 
     float ring[RING][NC];
@@ -360,6 +360,38 @@ __global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ 
             }
         }
     }
+}
+
+template <int S, int KS, int CW>
+__global__ __launch_bounds__(256) void k_prep_decim(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                     ptrdiff_t img_stride, int W, int H, int wk, int hk, int seg_rows,
+                                                     nsof_blur_taps t, float* __restrict__ out)
+{
+    prep_decim_body<S, KS, CW>(src, row_stride, img_stride, W, H, wk, hk, seg_rows, t, out, blockIdx.x,
+                               blockIdx.y * 4 + (threadIdx.x >> 6), blockIdx.z);
+}
+
+// Levels 1, 2, 3 of a pyr_scale 0.5 pyramid in ONE launch: twelve waves per workgroup, four per level, all over the same
+// 1024 (512) source columns and the same 4 x 96 source rows -- each level smooths the FULL-RES frame, so run as three
+// launches the frame crossed the fabric three times; side by side the second and third reader find its rows in the cache.
+// Same walks, same bits (prep_decim_body).
+struct Decim3 {
+    nsof_blur_taps t[3];
+    float* out[3];
+    int seg_rows[3];
+};
+template <int CW>
+__global__ __launch_bounds__(768) void k_prep_decim3(const uint8_t* __restrict__ src, ptrdiff_t row_stride,
+                                                      ptrdiff_t img_stride, int W, int H, Decim3 d)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int seg = blockIdx.y * 4 + (wave & 3);
+    if (wave < 4)
+        prep_decim_body<2, 3, CW>(src, row_stride, img_stride, W, H, W / 2, H / 2, d.seg_rows[0], d.t[0], d.out[0], blockIdx.x, seg, blockIdx.z);
+    else if (wave < 8)
+        prep_decim_body<4, 9, CW>(src, row_stride, img_stride, W, H, W / 4, H / 4, d.seg_rows[1], d.t[1], d.out[1], blockIdx.x, seg, blockIdx.z);
+    else
+        prep_decim_body<8, 19, CW>(src, row_stride, img_stride, W, H, W / 8, H / 8, d.seg_rows[2], d.t[2], d.out[2], blockIdx.x, seg, blockIdx.z);
 }
 
 // Resampled level, generic fallback: one thread per destination pixel, no data sharing.
@@ -1834,6 +1866,39 @@ void launch_polyexp_het_n(nsof_ctx* ctx, int n_img, const nsof_het_item* items, 
 // =========================================================================================
 // launchers
 // =========================================================================================
+// Levels 1..3 of a pyr_scale 0.5 pyramid in one launch (k_prep_decim3).  Returns NSOF_EUNSUPPORTED without launching
+// when the frames do not decimate exactly by 8 (or are not aligned for the vector walks): the caller then runs the
+// levels one by one.  out[k - 1]: level k's images, [n_img][H >> k][W >> k].
+int NSOF_PYR_NAME(nsof_launch_prep_decim3)(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride,
+                                           int W, int H, const nsof_blur_taps* taps, float* const* out)
+{
+    const int CWL = (W & 15) == 0 ? 16 : 8;
+    const bool ok = (W & 7) == 0 && (H & 7) == 0 && W >= 64 && H > 19 && (row_stride % CWL) == 0 && (img_stride % CWL) == 0 &&
+                    (reinterpret_cast<uintptr_t>(src) % CWL) == 0 && taps[0].ksize == 3 && taps[1].ksize == 9 &&
+                    taps[2].ksize == 19 && n_img <= 65535;
+    if (!ok) return NSOF_EUNSUPPORTED;
+    nsof_prof_scope ps(ctx, NSOF_K_PREP);
+    Decim3 d;
+    for (int k = 0; k < 3; k++) {
+        d.t[k] = taps[k];
+        d.out[k] = out[k];
+    }
+    // a wave's segment covers the same 96 source rows at every level (48 / 24 / 12 output rows: multiples of the walks'
+    // unroll counts 2 / 3 / 3); few images: shorter segments, as in the one-level launcher
+    int src_rows = 96;
+    const long waves_x = (W / CWL + 63) / 64;
+    while (src_rows > 24 && waves_x * ((H + src_rows - 1) / src_rows) * n_img < 1024) src_rows -= 24;
+    d.seg_rows[0] = src_rows / 2;
+    d.seg_rows[1] = src_rows / 4;
+    d.seg_rows[2] = src_rows / 8;
+    const int nseg = (H / 8 + d.seg_rows[2] - 1) / d.seg_rows[2];
+    dim3 grid((unsigned)waves_x, (nseg + 3) / 4, n_img);
+    if (CWL == 16) hipLaunchKernelGGL(k_prep_decim3<16>, grid, dim3(768), 0, ctx->stream, src, row_stride, img_stride, W, H, d);
+    else hipLaunchKernelGGL(k_prep_decim3<8>, grid, dim3(768), 0, ctx->stream, src, row_stride, img_stride, W, H, d);
+    NSOF_HIP(ctx, hipGetLastError());
+    return NSOF_OK;
+}
+
 int NSOF_PYR_NAME(nsof_launch_prep)(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
                      int H, int wk, int hk, const nsof_blur_taps& taps, float* out)
 {

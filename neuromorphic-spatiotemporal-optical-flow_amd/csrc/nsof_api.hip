@@ -817,7 +817,9 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
     // pyramid stages nor with the float expansion (their kernels have no such form).
     static const bool poly_u8_off = [] { const char* e = NSOF_AB_GETENV("NSOF_POLY_U8"); return e && e[0] == '0'; }();
     const bool poly_u8 = !poly_u8_off && !ctx->opt_pyr_fma && !ctx->opt_polyexp_f32 && width >= 2 && height >= 2;
+    float* Ifused[4] = {nullptr, nullptr, nullptr, nullptr};   // level images already made by the three-level launch
     auto level_expansion = [&](int k, int wk, int hk, const nsof_blur_taps& bt, float* I, float* Rk) -> int {
+        if (k >= 1 && k <= 3 && Ifused[k]) return nsof_launch_polyexp(ctx, (int)n_img, Ifused[k], wk, hk, ptaps, Rk);
         if (poly_u8 && k == 0 && bt.ksize == 3 && wk == width && hk == height) {
             const bool one = sequence || prep_merged;
             return nsof_launch_polyexp_u8(ctx, (int)n_img, d_prev, one ? d_prev : d_next, one ? (int)n_img : n_pairs, row_stride,
@@ -906,6 +908,37 @@ int nsof_farneback_core(nsof_ctx* ctx, bool sequence, int n_pairs, const uint8_t
         if (fl[c] != d_flow)
             NSOF_HIP(ctx, hipMemcpyAsync(d_flow, fl[c], B * n0 * 8, hipMemcpyDeviceToDevice, mainS));
         return NSOF_OK;
+    }
+
+    // pyr_scale 0.5 with three coarser levels (the headline configuration): levels 1..3 smooth and decimate the same
+    // full-resolution frames -- one launch makes all three (k_prep_decim3), into the level-image buffer that level 0 no
+    // longer needs before the coarser levels are done with it
+    static const bool decim3_off = [] { const char* e = NSOF_AB_GETENV("NSOF_DECIM3"); return e && e[0] == '0'; }();
+    if (L == 3 && !decim3_off) {
+        nsof_blur_taps bt3[3];
+        size_t nk3[3];
+        bool exact3 = true;
+        for (int k = 1; k <= 3 && exact3; k++) {
+            int wk, hk, ks;
+            double sg;
+            nsof_farneback_level_size(width, height, pyr_scale, k, &wk, &hk, &ks, &sg);
+            exact3 = wk * (1 << k) == width && hk * (1 << k) == height && nsof_host_blur_taps(ks, sg, &bt3[k - 1]) == 0;
+            nk3[k - 1] = (size_t)wk * hk;
+        }
+        if (exact3) {
+            float* I3[3] = {dI, dI + n_img * nk3[0], dI + n_img * (nk3[0] + nk3[1])};
+            const bool one = sequence || prep_merged;
+            rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_decim3, one ? (int)n_img : n_pairs, d_prev, row_stride, pair_stride, width, height, bt3, I3);
+            if (rc == NSOF_OK && !one) {
+                float* I3n[3] = {I3[0] + B * nk3[0], I3[1] + B * nk3[1], I3[2] + B * nk3[2]};
+                rc = NSOF_PYR_SEL(ctx, nsof_launch_prep_decim3, n_pairs, d_next, row_stride, pair_stride, width, height, bt3, I3n);
+            }
+            if (rc == NSOF_OK) {
+                for (int k = 1; k <= 3; k++) Ifused[k] = I3[k - 1];
+            } else if (rc != NSOF_EUNSUPPORTED) {
+                return rc;
+            }
+        }
     }
 
     bool have_prev = false;

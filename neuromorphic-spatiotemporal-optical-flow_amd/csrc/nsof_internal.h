@@ -185,6 +185,11 @@ int nsof_launch_prep(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row
 // multiply-add -- selected by ctx->opt_pyr_fma through the *_sel wrappers below.
 int nsof_launch_prep_fma(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
                          int H, int wk, int hk, const nsof_blur_taps& taps, float* out);
+// Levels 1..3 of a pyr_scale 0.5 pyramid in one launch; NSOF_EUNSUPPORTED (nothing launched) when the frames do not qualify.
+int nsof_launch_prep_decim3(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride, int W,
+                            int H, const nsof_blur_taps* taps, float* const* out);
+int nsof_launch_prep_decim3_fma(nsof_ctx* ctx, int n_img, const uint8_t* src, ptrdiff_t row_stride, ptrdiff_t img_stride,
+                                int W, int H, const nsof_blur_taps* taps, float* const* out);
 int nsof_launch_prep_het_fma(nsof_ctx* ctx, int n_items, const nsof_het_item* d_items, const nsof_het_item* h_items,
                              bool level0, const nsof_blur_taps& taps, float* I);
 int nsof_launch_flow_upsample_fma(nsof_ctx* ctx, int n_pairs, const float* src, int sw, int sh, float* dst, int dw,
