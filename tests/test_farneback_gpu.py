@@ -333,6 +333,39 @@ def test_fuzz_parameters_vs_oracle(nsof_lib, ctx, oracle):
     assert worst <= 1e-4
 
 
+@pytest.mark.parametrize("shape", [(256, 272), (264, 328), (1080, 1920)])
+def test_three_level_pyramid_launch_batch_and_sequence(nsof_lib, ctx, oracle, torch_dev, shape):
+    """pyr_scale 0.5 with three coarser levels on frames that decimate exactly by 8: the batch driver makes levels 1-3
+    in ONE launch (k_prep_decim3; 16- and 8-column lanes) and level 0 inside the expansion kernel.  A batch (prev and
+    next arrays apart: two launches) and a sequence (one array) through the fused-kernel path, against the oracle."""
+    import torch
+    from nsof import _lib, synth
+    h, w = shape
+    n = 2 if h > 1000 else 3
+    assert nsof_lib.effective_levels(w, h, 0.5, 3) == 3
+    base, _ = synth.make_pair(31, h + 16, w + 16)
+    frames = np.stack([np.ascontiguousarray(base[2 * i:2 * i + h, 3 * i:3 * i + w]) for i in range(n + 1)])
+    want = [oracle.farneback(frames[i], frames[i + 1], *A) for i in range(n)]
+    P = nsof_lib.FarnebackParams(*A)
+    ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 0)
+    try:
+        dp, dn = _dev(torch_dev, frames[:-1].copy()), _dev(torch_dev, frames[1:].copy())
+        df = torch.empty((n, h, w, 2), dtype=torch.float32, device=torch_dev)
+        nsof_lib.farneback_batch(dp, dn, df, n, h, w, P, ctx=ctx)
+        ctx.synchronize()
+        got = df.cpu().numpy()
+        ds = _dev(torch_dev, frames)
+        out = torch.empty((n, h, w, 2), dtype=torch.float32, device=torch_dev)
+        nsof_lib.farneback_sequence(ds, out, n + 1, h, w, P, ctx=ctx)
+        ctx.synchronize()
+        seq = out.cpu().numpy()
+    finally:
+        ctx.set_option(_lib.OPT_SMALL_BATCH_JOBS, 64)
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), ("batch", i, float(np.abs(got[i] - want[i]).max()))
+        assert np.array_equal(seq[i], want[i]), ("sequence", i, float(np.abs(seq[i] - want[i]).max()))
+
+
 def test_sequence_equals_consecutive_pairs(nsof_lib, ctx, torch_dev):
     """nsof_farneback_u8_sequence_dev == one call per consecutive pair, bit for bit (params A and B)."""
     import torch
