@@ -109,8 +109,15 @@ __global__ __launch_bounds__(64 * LC_WAVES) void k_lat_colsum(const float* __res
     };
     fetch(wave * LC_R);
     if (wave == 0) {
-        double vs = (double)(Mat(0) * (float)(m + 2));
-        for (int y = 1; y < m; y++) vs += (double)Mat(min(y, H - 1));
+        // the rows of the first window: loaded together (one memory latency, not m of them: this sum is the start of every
+        // launch's critical path, ~5 us of an 8 us launch at the coarse levels), added in the library's order
+        float mv[7];
+#pragma unroll
+        for (int y = 0; y < 7; y++) mv[y] = Mat(min(y, H - 1));
+        double vs = (double)(mv[0] * (float)(m + 2));
+#pragma unroll
+        for (int y = 1; y < 7; y++)
+            if (y < m) vs += (double)mv[y];
         carry[lane] = vs;
         if (lane == 0) {
             turns_done = 0;
