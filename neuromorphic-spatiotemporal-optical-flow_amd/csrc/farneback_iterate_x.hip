@@ -25,7 +25,9 @@
 //     behind strip s-1; nothing else couples them.
 //   * a workgroup takes its (pair, strip) job from a per-XCD ticket counter at start-up, in strip order, so the left
 //     neighbour of a running strip is itself running or done whatever order the hardware dispatches workgroups in
-//     (no assumption on dispatch order or placement; an XCD owning whole pairs is for L2 locality only).
+//     (no assumption on dispatch order or placement; an XCD owning whole pairs is for L2 locality only).  Work lists:
+//     the ticket indexes a host-built list of the (item, strip) jobs that exist, one list per XCD, an item's strips
+//     consecutive in one list (nsof_launch_iterate_x_het; farneback_batch.hip builds the lists).
 //
 // D / g are double-buffered, so within one step (ONE workgroup barrier) the scanner runs step t while the consumers solve
 // step t-1 out of the other buffer and then form and publish the column sums of step t+1 into it, and the producers
